@@ -1,0 +1,31 @@
+# Build of the product libraries and the test oracle.  `python -c "import __graft_entry__ as g; g.build()"` runs this.
+HIPCC    ?= /opt/rocm/bin/hipcc
+CC       ?= gcc
+ROOT     := $(dir $(abspath $(lastword $(MAKEFILE_LIST))))
+LIBDIR   := actinon_amd/lib
+CFLAGS   := -O2 -fPIC -std=gnu11 -Wall -Wno-unused-function -ffp-contract=off -Iinclude
+HIPFLAGS := -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Iinclude -Iactinon_amd/csrc -std=c++17 -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
+
+all: hip host oracle
+
+hip: $(LIBDIR)/libactinon_hip.so
+host: $(LIBDIR)/libactinon_host.so
+oracle: oracle/libacn_oracle.so oracle/libacn_oracle_libm.so
+
+$(LIBDIR)/libactinon_hip.so: actinon_amd/csrc/actinon_hip.hip $(wildcard actinon_amd/csrc/*.h) include/actinon_hip.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ actinon_amd/csrc/actinon_hip.hip
+
+$(LIBDIR)/libactinon_host.so: actinon_amd/host/acn_scene.c actinon_amd/host/acn_driver.c actinon_amd/host/acn_scenes.c include/acn_scene.h include/actinon_hip.h $(LIBDIR)/libactinon_hip.so
+	$(CC) $(CFLAGS) -shared -o $@ actinon_amd/host/acn_scene.c actinon_amd/host/acn_driver.c actinon_amd/host/acn_scenes.c -L$(LIBDIR) -lactinon_hip -lm -Wl,-rpath,'$$ORIGIN'
+
+oracle/libacn_oracle.so: oracle/acn_oracle.c oracle/acn_oracle.h actinon_amd/csrc/acn_detmath.h include/actinon_hip.h
+	$(CC) $(CFLAGS) -march=native -Ioracle -shared -o $@ oracle/acn_oracle.c -lm -lpthread
+
+oracle/libacn_oracle_libm.so: oracle/acn_oracle.c oracle/acn_oracle.h include/actinon_hip.h
+	$(CC) $(CFLAGS) -march=native -DACN_ORACLE_LIBM -Ioracle -shared -o $@ oracle/acn_oracle.c -lm -lpthread
+
+clean:
+	rm -f $(LIBDIR)/*.so oracle/*.so
+
+.PHONY: all hip host oracle clean

@@ -1,0 +1,1111 @@
+/* acn_device.h -- gfx950 device code of the trace / radiance path (included only by actinon_hip.hip).
+ *
+ * What the reference does with recursion over heap objects and vtables (src/objects.c, src/compound.c,
+ * src/scene.c:420-667) is done here with index-linked POD nodes, explicit per-lane stacks and state machines:
+ *   - hit_machine   : obj_ray_hit over CSG trees (pair_inside / pair_outside / neg / scale wrappers) as a
+ *                     coroutine-style state machine; all lanes of a wave that are "at a leaf" execute the same
+ *                     plane / sphere / squaroid / SDF code together regardless of their depth in the tree.
+ *   - side_machine  : obj_side as an iterative boolean-tree evaluation (short-circuited; children are pure).
+ *   - compound walk : closest hit / any hit / transition hit over (nested) compounds with an explicit stack.
+ *   - lum evaluator : scene_s_lum's branching recursion turned into a throughput-carrying work stack (pending
+ *                     rays) plus a small stack of suspended path loops.
+ * Floating-point expressions are written in the reference's order and compiled with -ffp-contract=off, so
+ * geometry, seeds and control flow are bit-identical to the CPU oracle; only the radiance sums are
+ * re-associated (throughput form), which moves colours by ~1e-16 relative.
+ */
+#ifndef ACN_DEVICE_H
+#define ACN_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include "actinon_hip.h"
+#include "acn_detmath.h"
+
+#pragma clang fp contract(off)
+
+#define DEV __device__ __forceinline__
+#define DEVN __device__ __noinline__
+
+#define F3_INF ( __builtin_huge_val() )
+#define F3_MAG 1E+30
+#define F3_EPS 1E-6
+#define ACN_PI 3.14159265358979323846
+
+#define ACN_CSG_MAX_DEPTH   24   /* nesting of pair / neg / scale wrappers */
+#define ACN_CMP_MAX_DEPTH   12   /* nesting of compounds */
+#define ACN_TASK_STACK      64   /* pending rays per lane */
+#define ACN_MAX_PATH_LEVELS 5    /* suspended path loops: trace_depth <= 10 * 5 + 10 */
+
+struct V3 { double x, y, z; };
+struct M3 { V3 x, y, z; };
+struct Ray { V3 p, d; };
+
+/* device-resident scene */
+struct DevScene
+{
+    const acn_node* nodes;
+    const int32_t*  elems;
+    int32_t light_root, matter_root;
+    uint32_t n_nodes, n_elems;
+    acn_params prm;
+    /* camera basis, computed on the device by k_camera_setup with the same expressions as the oracle */
+    M3 camera_rotation;
+    double unit_f;
+};
+
+enum
+{
+    CNT_TRANS_RAY = 0, CNT_SHADOW_RAY, CNT_OBJ_HIT, CNT_LUM, CNT_CAP_SAMPLE, CNT_SIDE, CNT_SDF_EVAL, CNT_OVERFLOW, CNT_N
+};
+
+struct Counters { unsigned long long c[ CNT_N ]; };
+
+/* ---- vectors.h ---- */
+DEV V3 mk( double x, double y, double z ) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
+DEV V3 ld3( const double* p ) { return mk( p[ 0 ], p[ 1 ], p[ 2 ] ); }
+DEV V3 v_neg( V3 o ) { return mk( -o.x, -o.y, -o.z ); }
+DEV double v_sqr( V3 o ) { return ( o.x * o.x ) + ( o.y * o.y ) + ( o.z * o.z ); }
+DEV V3 v_add( V3 o, V3 s ) { return mk( o.x + s.x, o.y + s.y, o.z + s.z ); }
+DEV V3 v_sub( V3 o, V3 s ) { return mk( o.x - s.x, o.y - s.y, o.z - s.z ); }
+DEV V3 v_mlf( V3 o, double f ) { return mk( o.x * f, o.y * f, o.z * f ); }
+DEV V3 v_mlx( V3 o, V3 f ) { return mk( o.y * f.z - o.z * f.y, o.z * f.x - o.x * f.z, o.x * f.y - o.y * f.x ); }
+DEV V3 v_mld( V3 o, V3 f ) { return mk( o.x * f.x, o.y * f.y, o.z * f.z ); }
+DEV double v_mlv( V3 o, V3 m ) { return ( o.x * m.x ) + ( o.y * m.y ) + ( o.z * m.z ); }
+DEV double v_sub_mlv( V3 o, V3 s, V3 m ) { return ( ( o.x - s.x ) * m.x ) + ( ( o.y - s.y ) * m.y ) + ( ( o.z - s.z ) * m.z ); }
+DEV double f_sqr( double a ) { return a * a; }
+DEV double v_diff_sqr( V3 o, V3 v ) { return f_sqr( o.x - v.x ) + f_sqr( o.y - v.y ) + f_sqr( o.z - v.z ); }
+DEV double f_max( double a, double b ) { return a > b ? a : b; }
+DEV double f_min( double a, double b ) { return a < b ? a : b; }
+DEV double f_abs( double a ) { return a < 0 ? -a : a; }
+
+DEV V3 v_of_length( V3 o, double a )   /* vectors.h:148-154 */
+{
+    double r_sqr = v_sqr( o );
+    if( acn_fabs( r_sqr - 1.0 ) < 1E-8 ) return o;
+    double f = r_sqr > 0 ? ( a / acn_sqrt( r_sqr ) ) : 0;
+    return mk( o.x * f, o.y * f, o.z * f );
+}
+
+DEV V3 v_von( V3 o, V3 v )   /* vectors.h:157-162 */
+{
+    V3 o_n = v_of_length( o, 1.0 );
+    v = v_sub( v, v_mlf( o_n, v_mlv( o_n, v ) ) );
+    return v_of_length( v, 1.0 );
+}
+
+DEV V3 v_con( V3 o )   /* vectors.h:165-175 */
+{
+    double xx = o.x * o.x;
+    double yy = o.y * o.y;
+    double zz = o.z * o.z;
+    V3 v;
+    v.x = ( ( xx <= yy ) && ( xx <= zz ) ) ? 1 : 0;
+    v.y = ( ( yy <= xx ) && ( yy <= zz ) ) ? 1 : 0;
+    v.z = ( ( zz <= xx ) && ( zz <= yy ) ) ? 1 : 0;
+    return v_von( o, v );
+}
+
+DEV V3 m_mlv( const M3& o, V3 v )   /* vectors.h:256-265 */
+{
+    return mk( o.x.x * v.x + o.x.y * v.y + o.x.z * v.z,
+               o.y.x * v.x + o.y.y * v.y + o.y.z * v.z,
+               o.z.x * v.x + o.z.y * v.y + o.z.z * v.z );
+}
+
+DEV V3 m_tmlv( const M3& o, V3 v )   /* vectors.h:268-276 */
+{
+    return mk( o.x.x * v.x + o.y.x * v.y + o.z.x * v.z,
+               o.x.y * v.x + o.y.y * v.y + o.z.y * v.z,
+               o.x.z * v.x + o.y.z * v.y + o.z.z * v.z );
+}
+
+DEV M3 m_transposed( const M3& o )
+{
+    M3 r;
+    r.x = mk( o.x.x, o.y.x, o.z.x );
+    r.y = mk( o.x.y, o.y.y, o.z.y );
+    r.z = mk( o.x.z, o.y.z, o.z.z );
+    return r;
+}
+
+DEV M3 m_con_z( V3 v )   /* vectors.h:315-322 */
+{
+    M3 m;
+    m.z = v_of_length( v, 1.0 );
+    m.x = v_con( v );
+    m.y = v_mlx( m.z, m.x );
+    return m;
+}
+
+DEV V3 ray_pos( V3 p, V3 d, double offs ) { return v_add( p, v_mlf( d, offs ) ); }   /* vectors.h:343-346 */
+
+DEV V3 v_orthogonal_projection( V3 o, V3 nor )   /* vectors.h:223-232 */
+{
+    double f = v_mlv( o, nor );
+    return mk( o.x - nor.x * f, o.y - nor.y * f, o.z - nor.z * f );
+}
+
+DEV V3 v_reflection( V3 dir, V3 nor )   /* vectors.h:238-241 */
+{
+    return v_of_length( v_sub( dir, v_mlf( nor, 2.0 * v_mlv( dir, nor ) ) ), 1.0 );
+}
+
+/* ---- LCG / sampling: vectors.h:45-48, 177-206 ---- */
+DEV uint64_t lcg00( uint64_t v ) { return v * ACN_LCG00_A + ACN_LCG00_C; }
+DEV uint64_t lcg01( uint64_t v ) { return v * ACN_LCG01_A + ACN_LCG01_C; }
+DEV uint64_t lcg02( uint64_t v ) { return v * ACN_LCG02_A + ACN_LCG02_C; }
+DEV double f3_rnd0( uint64_t* rv ) { return ( double )( *rv = lcg00( *rv ) ) * ( 2.0 / 0xFFFFFFFFFFFFFFFFull ) - 1.0; }
+DEV double f3_rnd1( uint64_t* rv ) { return ( double )( *rv = lcg00( *rv ) ) * ( 1.0 / 0xFFFFFFFFFFFFFFFFull ); }
+
+/* advance an lcg00 state by k steps in O(log k) (Brown's arbitrary-stride formula) */
+DEV uint64_t lcg00_jump( uint64_t v, uint64_t k )
+{
+    uint64_t a = ACN_LCG00_A, c = ACN_LCG00_C;
+    uint64_t acc_a = 1, acc_c = 0;
+    while( k )
+    {
+        if( k & 1 ) { acc_a *= a; acc_c = acc_c * a + c; }
+        c = ( a + 1 ) * c;
+        a *= a;
+        k >>= 1;
+    }
+    return acc_a * v + acc_c;
+}
+
+DEV uint64_t seed_from_f3( double v )
+{
+    int64_t seed_s3 = ( int64_t )( acn_frexp_mant( v ) * ( double )0x7FFFFFFFFFFFFFFF );
+    return ( uint64_t )seed_s3 * 27362149ull;
+}
+
+DEV uint64_t v_random_seed( V3 o, uint64_t rv )
+{
+    return seed_from_f3( o.x ) * lcg00( rv ) + seed_from_f3( o.y ) * lcg01( rv ) + seed_from_f3( o.z ) * lcg02( rv );
+}
+
+DEV V3 v_random_sphere_cap( uint64_t* rv, double h )
+{
+    V3 v;
+    double phi = 2.0 * ACN_PI * f3_rnd1( rv );
+    v.z = 1.0 - f3_rnd1( rv ) * h;
+    double scale = acn_sqrt( 1.0 - v.z * v.z );
+    double s, c;
+    acn_sincos( phi, &s, &c );
+    v.x = s * scale;
+    v.y = c * scale;
+    return v;
+}
+
+DEV V3 v_random_sphere_belt( uint64_t* rv, double h )   /* vectors.h:209-218 */
+{
+    V3 v;
+    double phi = 2.0 * ACN_PI * f3_rnd1( rv );
+    v.z = f3_rnd0( rv ) * h;
+    double scale = acn_sqrt( 1.0 - v.z * v.z );
+    double s, c;
+    acn_sincos( phi, &s, &c );
+    v.x = s * scale;
+    v.y = c * scale;
+    return v;
+}
+
+/* ---- gmath.h:38-97 ---- */
+DEV double plane_ray_hit( V3 pos, V3 nor, V3 rp, V3 rd, bool want_nor, V3* p_nor )
+{
+    double div = v_mlv( nor, rd );
+    if( div == 0 ) return F3_INF;
+    double offs = v_sub_mlv( pos, rp, nor ) / div;
+    if( want_nor ) *p_nor = nor;
+    return ( offs > 0 ) ? offs - F3_EPS : F3_INF;
+}
+
+DEV double sphere_ray_hit( V3 pos, double r, V3 rp, V3 rd, bool want_nor, V3* p_nor )
+{
+    V3 p = v_sub( rp, pos );
+    double s = v_mlv( p, rd );
+    double q = v_sqr( p ) - ( r * r );
+    double s2 = s * s;
+    if( s2 < q ) return F3_INF;
+    double offs = F3_INF;
+    if( s < 0 && q > 0 )
+    {
+        offs = -s - acn_sqrt( s2 - q ) - F3_EPS;
+    }
+    else if( s < 0 || q < 0 )
+    {
+        offs = -s + acn_sqrt( s2 - q ) - F3_EPS;
+    }
+    if( offs < F3_INF && want_nor ) *p_nor = v_of_length( v_sub( ray_pos( rp, rd, offs ), pos ), 1.0 );
+    return offs;
+}
+
+DEV int sphere_observer_side( V3 pos, double r, V3 observer )
+{
+    V3 diff = v_sub( observer, pos );
+    return ( v_sqr( diff ) > r * r ) ? 1 : -1;
+}
+
+/* ---- gmath.c:68-113 ---- */
+DEV double fresnel_reflection( V3 dir_i, V3 exit_nor, double trix, V3* dir )
+{
+    double c = v_mlv( dir_i, exit_nor );
+    double f = c < 0 ? trix : 1.0 / trix;
+    double cos_ai = acn_fabs( c );
+    cos_ai = cos_ai > 1.0 ? 1.0 : cos_ai;
+    double sin_ai = acn_sqrt( 1.0 - cos_ai * cos_ai );
+    double sin_at = sin_ai * f;
+    double reflectance = 1.0;
+    if( sin_at < 1 )
+    {
+        double cos_at = acn_sqrt( 1.0 - sin_at * sin_at );
+        double rs = f_sqr( ( f * cos_ai - cos_at ) / ( f * cos_ai + cos_at ) );
+        double rp = f_sqr( ( f * cos_at - cos_ai ) / ( f * cos_at + cos_ai ) );
+        reflectance = ( rs + rp ) * 0.5;
+    }
+    *dir = v_reflection( dir_i, exit_nor );
+    return reflectance;
+}
+
+DEV V3 fresnel_refraction( V3 dir_i, V3 exit_nor, double trix )
+{
+    double c = v_mlv( dir_i, exit_nor );
+    double f = c < 0 ? trix : 1.0 / trix;
+    double a = f;
+    double q = f * f * ( 1.0 - c * c );
+    if( q < 1.0 )
+    {
+        double b = -f * c + ( c > 0 ? acn_sqrt( 1.0 - q ) : -acn_sqrt( 1.0 - q ) );
+        return v_add( v_mlf( dir_i, a ), v_mlf( exit_nor, b ) );
+    }
+    return dir_i;
+}
+
+/* ---- node access ---- */
+DEV bool node_has_env( const acn_node* n ) { return ( n->flags & ACN_NODE_HAS_ENVELOPE ) != 0; }
+DEV M3 node_rax( const acn_node* n )
+{
+    M3 m;
+    m.x = ld3( n->rax ); m.y = ld3( n->rax + 3 ); m.z = ld3( n->rax + 6 );
+    return m;
+}
+DEV bool env_ray_hits( const acn_node* n, V3 rp, V3 rd )   /* objects.c:90-93 */
+{
+    return sphere_ray_hit( ld3( n->env_pos ), n->env_radius, rp, rd, false, nullptr ) < F3_INF;
+}
+DEV int env_side( const acn_node* n, V3 pos ) { return sphere_observer_side( ld3( n->env_pos ), n->env_radius, pos ); }
+
+/* ---- distance.c:39-42, 83-92 ---- */
+DEV double sdf_eval( const acn_node* n, V3 pos )
+{
+    if( n->sdf_kind == ACN_SDF_TORUS )
+    {
+        double x = pos.x;
+        double y = pos.y;
+        double f = acn_sqrt( x * x + y * y );
+        double f_inv = ( f > 0 ) ? ( 1.0 / f ) : 1.0;
+        x *= f_inv;
+        y *= f_inv;
+        return acn_sqrt( f_sqr( x - pos.x ) + f_sqr( y - pos.y ) + f_sqr( pos.z ) ) - n->prm[ 1 ];
+    }
+    return acn_sqrt( f_sqr( pos.x ) + f_sqr( pos.y ) + f_sqr( pos.z ) ) - 1.0;
+}
+
+/* ---- leaves ---- */
+DEV double squaroid_ray_hit( const acn_node* o, V3 rp, V3 rd, bool want_nor, V3* p_nor )   /* objects.c:778-821 */
+{
+    M3 rax = node_rax( o );
+    double oa = o->prm[ 0 ], ob = o->prm[ 1 ], oc = o->prm[ 2 ], orr = o->prm[ 3 ];
+    V3 p = m_mlv( rax, v_sub( rp, ld3( o->pos ) ) );
+    V3 d = m_mlv( rax, rd );
+    double f  = oa * d.x * d.x + ob * d.y * d.y + oc * d.z * d.z;
+    double fs = oa * d.x * p.x + ob * d.y * p.y + oc * d.z * p.z;
+    double fq = oa * p.x * p.x + ob * p.y * p.y + oc * p.z * p.z + orr;
+    double a = F3_INF;
+    if( f != 0 )
+    {
+        double f_inv = 1.0 / f;
+        double s = fs * f_inv;
+        double q = fq * f_inv;
+        double rr = s * s - q;
+        if( rr < 0 ) return F3_INF;
+        rr = acn_sqrt( rr );
+        a = -s - rr;
+        if( a < 0 ) a = -s + rr;
+        if( a < 0 ) a = F3_INF;
+    }
+    else
+    {
+        a = ( fq != 0 ) ? -fs / ( 2 * fq ) : F3_INF;
+    }
+    if( a == F3_INF ) return F3_INF;
+    if( want_nor )
+    {
+        double x = p.x + a * d.x;
+        double y = p.y + a * d.y;
+        double z = p.z + a * d.z;
+        V3 n1 = mk( x * oa, y * ob, z * oc );
+        *p_nor = v_of_length( m_tmlv( rax, n1 ), 1.0 );
+    }
+    return a - F3_EPS;
+}
+
+DEV int squaroid_side( const acn_node* o, V3 pos )   /* objects.c:823-827 */
+{
+    M3 rax = node_rax( o );
+    V3 p = m_mlv( rax, v_sub( pos, ld3( o->pos ) ) );
+    return ( o->prm[ 0 ] * p.x * p.x + o->prm[ 1 ] * p.y * p.y + o->prm[ 2 ] * p.z * p.z + o->prm[ 3 ] ) > 0 ? 1 : -1;
+}
+
+DEVN double distance_ray_hit( const acn_node* o, V3 rp, V3 rd, bool want_nor, V3* p_nor, Counters* cnt )   /* objects.c:903-959 */
+{
+    M3 rax = node_rax( o );
+    double inv_scale = o->prm[ 0 ];
+    V3 p = rp;
+    double offs0 = 0;
+    if( node_has_env( o ) )
+    {
+        if( env_side( o, rp ) == 1 )
+        {
+            offs0 = sphere_ray_hit( ld3( o->env_pos ), o->env_radius, rp, rd, false, nullptr );
+            if( offs0 >= F3_INF ) return F3_INF;
+            p = ray_pos( rp, rd, offs0 );
+        }
+    }
+    p = v_mlf( m_mlv( rax, v_sub( p, ld3( o->pos ) ) ), inv_scale );
+    V3 d = m_mlv( rax, rd );
+
+    double offs1 = 0;
+    double dist = sdf_eval( o, p );
+    unsigned evals = 1;
+    int cycles = o->cycles;
+    if( dist > 0 )
+    {
+        for( int i = 0; i < cycles; i++ )
+        {
+            offs1 += dist + F3_EPS;
+            dist = sdf_eval( o, ray_pos( p, d, offs1 ) );
+            evals++;
+            if( dist < 0 || dist > F3_MAG ) break;
+        }
+    }
+    else
+    {
+        for( int i = 0; i < cycles; i++ )
+        {
+            offs1 -= dist - F3_EPS;
+            dist = sdf_eval( o, ray_pos( p, d, offs1 ) );
+            evals++;
+            if( dist > 0 || dist < -F3_MAG ) break;
+        }
+    }
+    cnt->c[ CNT_SDF_EVAL ] += evals;
+    if( f_abs( dist ) <= F3_EPS )
+    {
+        if( want_nor )
+        {
+            V3 q = ray_pos( p, d, offs1 );
+            double d0 = sdf_eval( o, q );
+            V3 n;
+            n.x = ( sdf_eval( o, mk( q.x + F3_EPS, q.y, q.z ) ) - d0 ) / F3_EPS;
+            n.y = ( sdf_eval( o, mk( q.x, q.y + F3_EPS, q.z ) ) - d0 ) / F3_EPS;
+            n.z = ( sdf_eval( o, mk( q.x, q.y, q.z + F3_EPS ) ) - d0 ) / F3_EPS;
+            *p_nor = v_of_length( m_tmlv( rax, n ), 1.0 );
+        }
+        return offs0 + ( offs1 / inv_scale ) - F3_EPS;
+    }
+    return F3_INF;
+}
+
+DEV int distance_side( const acn_node* o, V3 pos )   /* objects.c:961-966 */
+{
+    if( node_has_env( o ) && env_side( o, pos ) == 1 ) return 1;
+    M3 rax = node_rax( o );
+    V3 p = v_mlf( m_mlv( rax, v_sub( pos, ld3( o->pos ) ) ), o->prm[ 0 ] );
+    return sdf_eval( o, p ) > 0 ? 1 : -1;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* side machine: obj_side (objects.c:365-370) over the CSG tree, iteratively. */
+struct SideFrame { int node; int pc; V3 pos; };
+
+DEVN int obj_side_dev( const DevScene& sc, int root, V3 pos, Counters* cnt )
+{
+    SideFrame st[ ACN_CSG_MAX_DEPTH ];
+    int sp = 0;
+    int node = root;
+    int r = 1;
+    for( ;; )
+    {
+        /* ENTER( node, pos ) */
+        const acn_node* n = &sc.nodes[ node ];
+        cnt->c[ CNT_SIDE ]++;
+        bool returned = true;
+        if( node_has_env( n ) && env_side( n, pos ) == 1 )
+        {
+            r = 1;
+        }
+        else
+        {
+            switch( n->type )
+            {
+                case ACN_PLANE:    r = v_sub_mlv( pos, ld3( n->pos ), ld3( n->rax + 6 ) ) > 0 ? 1 : -1; break;   /* gmath.h:52-55 */
+                case ACN_SPHERE:   r = sphere_observer_side( ld3( n->pos ), n->prm[ 0 ], pos ); break;
+                case ACN_SQUAROID: r = squaroid_side( n, pos ); break;
+                case ACN_DISTANCE: r = distance_side( n, pos ); cnt->c[ CNT_SDF_EVAL ]++; break;
+                case ACN_PAIR_INSIDE: case ACN_PAIR_OUTSIDE: case ACN_NEG:
+                    if( sp >= ACN_CSG_MAX_DEPTH ) { cnt->c[ CNT_OVERFLOW ]++; r = 1; break; }
+                    st[ sp ].node = node; st[ sp ].pc = 1; st[ sp ].pos = pos; sp++;
+                    node = n->child0;
+                    returned = false;
+                    break;
+                case ACN_SCALE:   /* objects.c:1439-1443 */
+                {
+                    if( sp >= ACN_CSG_MAX_DEPTH ) { cnt->c[ CNT_OVERFLOW ]++; r = 1; break; }
+                    st[ sp ].node = node; st[ sp ].pc = 1; st[ sp ].pos = pos; sp++;
+                    M3 rax = node_rax( n );
+                    V3 p = m_mlv( rax, v_sub( pos, ld3( n->pos ) ) );
+                    pos = v_mld( p, mk( n->prm[ 0 ], n->prm[ 1 ], n->prm[ 2 ] ) );
+                    node = n->child0;
+                    returned = false;
+                    break;
+                }
+                default: r = 1; break;
+            }
+        }
+        /* RETURN( r ) */
+        while( returned )
+        {
+            if( sp == 0 ) return r;
+            SideFrame& f = st[ sp - 1 ];
+            const acn_node* fn = &sc.nodes[ f.node ];
+            if( fn->type == ACN_NEG ) { r = -r; sp--; }                                   /* objects.c:1341-1344 */
+            else if( fn->type == ACN_SCALE ) { sp--; }
+            else
+            {
+                int want = ( fn->type == ACN_PAIR_INSIDE ) ? -1 : 1;   /* objects.c:1096-1099, 1253-1256 */
+                if( f.pc == 1 )
+                {
+                    if( r != want ) { r = -want; sp--; }
+                    else { f.pc = 2; node = fn->child1; pos = f.pos; returned = false; }
+                }
+                else
+                {
+                    r = ( r == want ) ? want : -want;
+                    sp--;
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* hit machine: obj_ray_hit (objects.c:261-284) with pair / neg / scale recursion unrolled into frames. */
+struct HitFrame
+{
+    int node; int pc; int swapped; int pad;
+    double a1;        /* pair: a1 | scale: d_factor */
+    double offs;      /* pair: a2, later the walk offset */
+    V3 n1;            /* pair: n1 | scale: saved ray direction */
+    V3 n2;
+    V3 rp;            /* origin of the ray this call received */
+};
+
+DEV V3 roughness_normal( const acn_node* hdr, V3 n, V3 hit_pos )   /* objects.c:267-282 */
+{
+    uint64_t rv = v_random_seed( hit_pos, 1246 );
+    double f;
+    f = f3_rnd0( &rv ) * 0.99;
+    n.x += hdr->surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
+    f = f3_rnd0( &rv ) * 0.99;
+    n.y += hdr->surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
+    f = f3_rnd0( &rv ) * 0.99;
+    n.z += hdr->surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
+    return v_of_length( n, 1.0 );
+}
+
+DEVN double obj_ray_hit_dev( const DevScene& sc, int root, V3 rp, V3 rd, bool want_nor, V3* out_nor, Counters* cnt )
+{
+    /* fast path: a leaf needs no frame */
+    HitFrame st[ ACN_CSG_MAX_DEPTH ];
+    int sp = 0;
+    int node = root;
+    double ret_a = F3_INF;
+    V3 ret_n = mk( 0, 0, 0 );
+    for( ;; )
+    {
+        /* ---- ENTER( node, rp, rd ) ---- */
+        const acn_node* n = &sc.nodes[ node ];
+        cnt->c[ CNT_OBJ_HIT ]++;
+        bool returned = true;   /* false: a child call was issued */
+        if( node_has_env( n ) && !env_ray_hits( n, rp, rd ) )
+        {
+            ret_a = F3_INF;
+        }
+        else
+        {
+            switch( n->type )
+            {
+                case ACN_PLANE:    ret_a = plane_ray_hit( ld3( n->pos ), ld3( n->rax + 6 ), rp, rd, want_nor, &ret_n ); break;
+                case ACN_SPHERE:   ret_a = sphere_ray_hit( ld3( n->pos ), n->prm[ 0 ], rp, rd, want_nor, &ret_n ); break;
+                case ACN_SQUAROID: ret_a = squaroid_ray_hit( n, rp, rd, want_nor, &ret_n ); break;
+                case ACN_DISTANCE: ret_a = distance_ray_hit( n, rp, rd, want_nor, &ret_n, cnt ); break;
+                case ACN_PAIR_INSIDE: case ACN_PAIR_OUTSIDE: case ACN_NEG:
+                    if( sp >= ACN_CSG_MAX_DEPTH ) { cnt->c[ CNT_OVERFLOW ]++; ret_a = F3_INF; break; }
+                    st[ sp ].node = node; st[ sp ].pc = 1; st[ sp ].swapped = 0; st[ sp ].rp = rp; sp++;
+                    node = n->child0;
+                    returned = false;
+                    break;
+                case ACN_SCALE:   /* objects.c:1418-1428 */
+                {
+                    if( sp >= ACN_CSG_MAX_DEPTH ) { cnt->c[ CNT_OVERFLOW ]++; ret_a = F3_INF; break; }
+                    M3 rax = node_rax( n );
+                    V3 inv_scale = mk( n->prm[ 0 ], n->prm[ 1 ], n->prm[ 2 ] );
+                    V3 p2 = v_mld( m_mlv( rax, v_sub( rp, ld3( n->pos ) ) ), inv_scale );
+                    V3 d2 = v_mld( m_mlv( rax, rd ), inv_scale );
+                    double d_length = acn_sqrt( v_sqr( d2 ) );
+                    double d_factor = ( d_length > 0 ) ? ( 1.0 / d_length ) : 0;
+                    d2 = v_mlf( d2, d_factor );
+                    st[ sp ].node = node; st[ sp ].pc = 1; st[ sp ].rp = rp; st[ sp ].n1 = rd; st[ sp ].a1 = d_factor; sp++;
+                    rp = p2; rd = d2;
+                    node = n->child0;
+                    returned = false;
+                    break;
+                }
+                default: ret_a = F3_INF; break;
+            }
+        }
+
+        /* ---- POST + RETURN: unwind while results are final ---- */
+        while( returned )
+        {
+            /* POST of `node` called with ( rp, rd ): roughness, objects.c:266-282 */
+            {
+                const acn_node* hdr = &sc.nodes[ node ];
+                if( want_nor && ret_a < F3_INF && hdr->surface_roughness > 0 )
+                {
+                    ret_n = roughness_normal( hdr, ret_n, ray_pos( rp, rd, ret_a ) );
+                }
+            }
+            if( sp == 0 )
+            {
+                if( want_nor ) *out_nor = ret_n;
+                return ret_a;
+            }
+            HitFrame& f = st[ sp - 1 ];
+            const acn_node* fn = &sc.nodes[ f.node ];
+            if( fn->type == ACN_NEG )   /* objects.c:1329-1339 */
+            {
+                if( ret_a < F3_INF ) ret_n = v_neg( ret_n );
+                node = f.node; rp = f.rp; sp--;
+            }
+            else if( fn->type == ACN_SCALE )   /* objects.c:1430-1437 */
+            {
+                double a1 = ret_a + F3_EPS;
+                rd = f.n1;
+                if( a1 < F3_INF )
+                {
+                    if( want_nor )
+                    {
+                        V3 n1 = v_mld( ret_n, mk( fn->prm[ 0 ], fn->prm[ 1 ], fn->prm[ 2 ] ) );
+                        ret_n = v_of_length( m_tmlv( node_rax( fn ), n1 ), 1.0 );
+                    }
+                    ret_a = a1 * f.a1 - F3_EPS;
+                }
+                else
+                {
+                    ret_a = F3_INF;
+                }
+                node = f.node; rp = f.rp; sp--;
+            }
+            else   /* pair: objects.c:1052-1094 / 1209-1251 */
+            {
+                int want = ( fn->type == ACN_PAIR_INSIDE ) ? -1 : 1;
+                if( f.pc == 1 )
+                {
+                    f.a1 = ret_a; f.n1 = ret_n; f.pc = 2;
+                    node = fn->child1; rp = f.rp;
+                    returned = false;
+                }
+                else if( f.pc == 2 )
+                {
+                    double a1 = f.a1, a2 = ret_a;
+                    if( a1 < a2 && obj_side_dev( sc, fn->child1, ray_pos( f.rp, rd, a1 ), cnt ) == want )
+                    {
+                        ret_a = a1; ret_n = f.n1;
+                        node = f.node; rp = f.rp; sp--;
+                    }
+                    else if( a2 >= F3_INF )
+                    {
+                        ret_a = F3_INF;
+                        node = f.node; rp = f.rp; sp--;
+                    }
+                    else if( obj_side_dev( sc, fn->child0, ray_pos( f.rp, rd, a2 ), cnt ) == want )
+                    {
+                        /* ret_a = a2, ret_n = n2 already */
+                        node = f.node; rp = f.rp; sp--;
+                    }
+                    else
+                    {
+                        f.offs = a2; f.swapped = 0; f.pc = 3;
+                        node = fn->child0; rp = ray_pos( f.rp, rd, f.offs );
+                        returned = false;
+                    }
+                }
+                else
+                {
+                    double a = ret_a;
+                    if( a >= F3_INF )
+                    {
+                        ret_a = F3_INF;
+                        node = f.node; rp = f.rp; sp--;
+                    }
+                    else
+                    {
+                        V3 walk_p = ray_pos( f.rp, rd, f.offs );
+                        int obj2 = f.swapped ? fn->child0 : fn->child1;
+                        if( obj_side_dev( sc, obj2, ray_pos( walk_p, rd, a ), cnt ) == want )
+                        {
+                            ret_a = f.offs + a;   /* ret_n = n1 of the last child call */
+                            node = f.node; rp = f.rp; sp--;
+                        }
+                        else
+                        {
+                            f.offs += a + 2 * F3_EPS;
+                            if( !( f.offs < F3_INF ) )
+                            {
+                                ret_a = F3_INF;
+                                node = f.node; rp = f.rp; sp--;
+                            }
+                            else
+                            {
+                                f.swapped ^= 1;
+                                node = f.swapped ? fn->child1 : fn->child0;
+                                rp = ray_pos( f.rp, rd, f.offs );
+                                returned = false;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* compounds: compound.c:215-299 */
+
+/* closest hit inside compound `cmp` (recursing into nested compounds). limit: stop as soon as a hit <= limit is
+ * found (any-hit for occlusion: "compound_s_ray_hit( matter ) > a" is false iff some element hits at <= a). */
+DEVN double compound_ray_hit_dev( const DevScene& sc, int cmp, V3 rp, V3 rd, bool want_nor, V3* p_nor, int* hit_obj,
+                                  double limit, Counters* cnt )
+{
+    int st_i[ ACN_CMP_MAX_DEPTH ], st_end[ ACN_CMP_MAX_DEPTH ];
+    int sp = 0;
+    double min_a = F3_INF;
+    {
+        const acn_node* o = &sc.nodes[ cmp ];
+        if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) return F3_INF;
+        st_i[ 0 ] = o->child0; st_end[ 0 ] = o->child0 + o->child1; sp = 1;
+    }
+    while( sp > 0 )
+    {
+        if( st_i[ sp - 1 ] >= st_end[ sp - 1 ] ) { sp--; continue; }
+        int element = sc.elems[ st_i[ sp - 1 ]++ ];
+        const acn_node* e = &sc.nodes[ element ];
+        if( e->type == ACN_COMPOUND )
+        {
+            if( node_has_env( e ) && !env_ray_hits( e, rp, rd ) ) continue;
+            if( sp >= ACN_CMP_MAX_DEPTH ) { cnt->c[ CNT_OVERFLOW ]++; continue; }
+            st_i[ sp ] = e->child0; st_end[ sp ] = e->child0 + e->child1; sp++;
+            continue;
+        }
+        V3 nor;
+        double a = obj_ray_hit_dev( sc, element, rp, rd, want_nor, &nor, cnt );
+        if( a < min_a )
+        {
+            min_a = a;
+            if( want_nor ) *p_nor = nor;
+            if( hit_obj ) *hit_obj = element;
+            if( a <= limit ) return a;
+        }
+    }
+    return min_a;
+}
+
+struct Trans { V3 exit_nor; int exit_obj; int enter_obj; };
+
+DEVN double compound_ray_trans_hit_dev( const DevScene& sc, int cmp, V3 rp, V3 rd, Trans* trans, Counters* cnt )
+{
+    const acn_node* o = &sc.nodes[ cmp ];
+    cnt->c[ CNT_TRANS_RAY ]++;
+    if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) return F3_INF;
+    double min_a = F3_INF;
+    int first = o->child0, count = o->child1;
+    for( int i = 0; i < count; i++ )
+    {
+        int element = sc.elems[ first + i ];
+        int hit_obj = -1;
+        V3 nor = mk( 0, 0, 0 );
+        double a;
+        if( sc.nodes[ element ].type == ACN_COMPOUND )
+        {
+            a = compound_ray_hit_dev( sc, element, rp, rd, true, &nor, &hit_obj, -F3_INF, cnt );
+        }
+        else
+        {
+            hit_obj = element;
+            a = obj_ray_hit_dev( sc, element, rp, rd, true, &nor, cnt );
+        }
+        if( a < F3_INF )
+        {
+            if( a < min_a - F3_EPS )
+            {
+                min_a = a;
+                if( v_mlv( nor, rd ) > 0 )
+                {
+                    trans->exit_nor = nor; trans->exit_obj = hit_obj; trans->enter_obj = -1;
+                }
+                else
+                {
+                    trans->exit_nor = v_neg( nor ); trans->exit_obj = -1; trans->enter_obj = hit_obj;
+                }
+            }
+            else if( f_abs( a - min_a ) < F3_EPS )
+            {
+                min_a = a < min_a ? a : min_a;
+                if( v_mlv( nor, rd ) > 0 ) trans->exit_obj = hit_obj;
+                else                       trans->enter_obj = hit_obj;
+            }
+        }
+    }
+    return min_a;
+}
+
+DEV double scene_trans_hit_dev( const DevScene& sc, V3 rp, V3 rd, Trans* trans, Counters* cnt )   /* scene.c:362-382 */
+{
+    double min_a = F3_INF;
+    double a;
+    Trans trans_l;
+    trans_l.exit_nor = mk( 0, 0, 0 ); trans_l.exit_obj = -1; trans_l.enter_obj = -1;
+    if( ( a = compound_ray_trans_hit_dev( sc, sc.light_root, rp, rd, &trans_l, cnt ) ) < min_a )
+    {
+        min_a = a;
+        *trans = trans_l;
+    }
+    if( ( a = compound_ray_trans_hit_dev( sc, sc.matter_root, rp, rd, &trans_l, cnt ) ) < min_a )
+    {
+        min_a = a;
+        *trans = trans_l;
+    }
+    return min_a;
+}
+
+/* ---- fov of a light: objects.c:254-259 -> :520-527, :619-637, :1035-1045 ---- */
+DEV void sphere_fov( V3 center, double radius, V3 pos, V3* dir, double* cos_rs )
+{
+    V3 diff = v_sub( center, pos );
+    *dir = v_of_length( diff, 1.0 );
+    double diff_sqr = v_sqr( diff );
+    double radius_sqr = f_sqr( radius );
+    *cos_rs = ( diff_sqr > radius_sqr ) ? acn_sqrt( 1.0 - ( radius_sqr / diff_sqr ) ) : -1;
+}
+
+DEV void obj_fov_dev( const acn_node* o, V3 pos, V3* dir, double* cos_rs )
+{
+    if( o->type == ACN_PLANE )
+    {
+        *dir = v_neg( ld3( o->rax + 6 ) );
+        *cos_rs = v_mlv( v_sub( ld3( o->pos ), pos ), *dir ) > 0 ? 0 : 1;
+    }
+    else if( o->type == ACN_SPHERE )
+    {
+        sphere_fov( ld3( o->pos ), o->prm[ 0 ], pos, dir, cos_rs );
+    }
+    else if( node_has_env( o ) )
+    {
+        sphere_fov( ld3( o->env_pos ), o->env_radius, pos, dir, cos_rs );
+    }
+    else
+    {
+        *dir = v_of_length( v_sub( ld3( o->pos ), pos ), 1.0 );
+        *cos_rs = 0;
+    }
+}
+
+/* scene.c:394-416 */
+DEV double oren_nayar_weight( double weight, double theta_i, double on_a, double on_b, V3 out_d, V3 nor, V3 ray_prj )
+{
+    double theta_r = acn_acos( weight );
+    double cos_phi = -v_mlv( v_of_length( v_orthogonal_projection( out_d, nor ), 1.0 ), ray_prj );
+    double ta = f_max( theta_i, theta_r ), tb = f_min( theta_i, theta_r );
+    double s1, c1, s2, c2;
+    acn_sincos( ta, &s1, &c1 );
+    acn_sincos( tb, &s2, &c2 );
+    return weight * ( on_a + ( on_b * f_max( cos_phi, 0 ) * s1 * ( s2 / c2 ) ) );
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* the shading context of one diffuse shading point (scene.c:526-537) */
+struct ShadeCtx
+{
+    V3 pos;              /* surface.p */
+    V3 surface_d;        /* -exit_nor */
+    V3 ray_projection;
+    double theta_i, on_a, on_b;
+    double diffuse_intensity;
+};
+
+/* one direct-light sample j of light `light_idx` (scene.c:556-576); returns its contribution to cl_sum / color */
+DEV double direct_sample( const DevScene& sc, const ShadeCtx& s, int light_idx, const acn_node* light_src, const M3& src_con,
+                          double cyl_hgt, uint64_t* rv, Counters* cnt )
+{
+    cnt->c[ CNT_CAP_SAMPLE ]++;
+    V3 out_d = m_mlv( src_con, v_random_sphere_cap( rv, cyl_hgt ) );
+    double weight = v_mlv( out_d, s.surface_d );
+    if( weight <= 0 ) return 0;
+    double a = obj_ray_hit_dev( sc, light_idx, s.pos, out_d, false, nullptr, cnt );
+    if( a >= F3_INF ) return 0;
+    if( s.on_b > 0 ) weight = oren_nayar_weight( weight, s.theta_i, s.on_a, s.on_b, out_d, s.surface_d, s.ray_projection );
+    cnt->c[ CNT_SHADOW_RAY ]++;
+    if( compound_ray_hit_dev( sc, sc.matter_root, s.pos, out_d, false, nullptr, nullptr, a, cnt ) > a )
+    {
+        V3 hit_pos = ray_pos( s.pos, out_d, a );
+        double diff_sqr = v_diff_sqr( hit_pos, ld3( light_src->pos ) );
+        double local_intensity = ( diff_sqr > 0 ) ? ( light_src->radiance / diff_sqr ) : F3_MAG;
+        return local_intensity * weight * s.diffuse_intensity;
+    }
+    return 0;
+}
+
+/* pending ray of the lum evaluator */
+struct RayTask
+{
+    V3 p, d;
+    V3 T;               /* colour throughput applied to whatever this ray returns */
+    double intensity;
+    int depth;
+    int kind;           /* 0: scene_s_trans_hit ray (reflection/refraction/primary); 1: path ray (matter only) */
+};
+
+/* suspended path loop (scene.c:584-621) */
+struct PathFrame
+{
+    ShadeCtx s;
+    M3 out_con;
+    V3 T;               /* T_parent * enter_color * ( 2.0 / path_samples ) */
+    uint64_t rv;
+    uint64_t i, n;
+    int depth;
+};
+
+DEV void acc_add( V3* acc, V3 T, V3 c )
+{
+    acc->x += T.x * c.x; acc->y += T.y * c.y; acc->z += T.z * c.z;
+}
+
+/* Serial (one lane) evaluation of scene_s_lum for the ray tree rooted at `root`. Adds into *acc. */
+DEVN void lum_serial( const DevScene& sc, RayTask root, V3* acc, Counters* cnt )
+{
+    RayTask tasks[ ACN_TASK_STACK ];
+    PathFrame frames[ ACN_MAX_PATH_LEVELS ];
+    int tsp = 0, fsp = 0;
+    tasks[ tsp++ ] = root;
+    const double min_intensity = sc.prm.trace_min_intensity;
+    const V3 bg = ld3( sc.prm.background_color );
+
+    for( ;; )
+    {
+        if( tsp == 0 )
+        {
+            if( fsp == 0 ) return;
+            /* advance the innermost suspended path loop by one sample */
+            PathFrame& f = frames[ fsp - 1 ];
+            if( f.i >= f.n ) { fsp--; continue; }
+            f.i++;
+            cnt->c[ CNT_CAP_SAMPLE ]++;
+            V3 out_d = m_mlv( f.out_con, v_random_sphere_cap( &f.rv, 1.0 ) );
+            double weight = v_mlv( out_d, f.s.surface_d );
+            if( weight <= 0 ) continue;
+            if( f.s.on_b > 0 ) weight = oren_nayar_weight( weight, f.s.theta_i, f.s.on_a, f.s.on_b, out_d, f.s.surface_d, f.s.ray_projection );
+            RayTask t;
+            t.p = f.s.pos; t.d = out_d; t.T = f.T; t.intensity = weight * f.s.diffuse_intensity; t.depth = f.depth - 10; t.kind = 1;
+            tasks[ tsp++ ] = t;
+            continue;
+        }
+
+        RayTask t = tasks[ --tsp ];
+        Trans trans;
+        trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
+        double offs;
+        if( t.kind == 0 )
+        {
+            offs = scene_trans_hit_dev( sc, t.p, t.d, &trans, cnt );
+            if( !( offs < F3_INF ) ) { acc_add( acc, t.T, v_mlf( bg, t.intensity ) ); continue; }
+        }
+        else
+        {
+            offs = compound_ray_trans_hit_dev( sc, sc.matter_root, t.p, t.d, &trans, cnt );
+            if( !( offs < sc.prm.max_path_length ) ) { acc_add( acc, t.T, v_mlf( bg, t.intensity ) ); continue; }
+        }
+
+        /* ---- scene_s_lum( ray = t, offs, trans, depth, intensity ) scene.c:420-667 ---- */
+        int depth = t.depth;
+        double intensity = t.intensity;
+        if( depth == 0 || intensity < min_intensity ) continue;
+        cnt->c[ CNT_LUM ]++;
+        V3 pos = ray_pos( t.p, t.d, offs );
+        const acn_node* enter_obj = trans.enter_obj >= 0 ? &sc.nodes[ trans.enter_obj ] : nullptr;
+        const acn_node* exit_obj  = trans.exit_obj  >= 0 ? &sc.nodes[ trans.exit_obj  ] : nullptr;
+
+        if( enter_obj && enter_obj->radiance > 0 )
+        {
+            double diff_sqr = v_diff_sqr( pos, ld3( enter_obj->pos ) );
+            double light_intensity = ( diff_sqr > 0 ) ? ( enter_obj->radiance / diff_sqr ) : F3_MAG;
+            acc_add( acc, t.T, v_mlf( ld3( enter_obj->color ), light_intensity * intensity ) );
+            continue;
+        }
+
+        double trix = 1.0;
+        double fresnel_reflectivity = 0, chromatic_reflectivity = 0, diffuse_reflectivity = 0;
+        double on_a = 1.0, on_b = 0.0;
+        bool transparent = false;
+        V3 enter_color = mk( 1, 1, 1 );
+        if( enter_obj )
+        {
+            trix = enter_obj->refractive_index;
+            fresnel_reflectivity   = ( enter_obj->fresnel_reflectivity != 0 && enter_obj->refractive_index != 1.0 ) ? 1.0 : 0.0;
+            chromatic_reflectivity = enter_obj->chromatic_reflectivity;
+            diffuse_reflectivity   = enter_obj->diffuse_reflectivity;
+            transparent            = v_sqr( ld3( enter_obj->transparency ) ) > 0;
+            double sigma           = enter_obj->sigma;
+            if( sigma > 0 )
+            {
+                double sigma_sqr = f_sqr( sigma );
+                on_a = 1.0 - 0.5 * sigma_sqr / ( sigma_sqr + 0.33 );
+                on_b = 0.45 * sigma_sqr / ( sigma_sqr + 0.09 );
+            }
+            enter_color = ld3( enter_obj->color );
+        }
+        V3 T = t.T;
+        if( exit_obj )
+        {
+            trix /= exit_obj->refractive_index;
+            fresnel_reflectivity = 1.0;
+            diffuse_reflectivity = chromatic_reflectivity = 0;
+            transparent = true;
+            /* exiting object scene.c:656-664: the absorption factor multiplies everything this call returns */
+            if( offs > 0 )
+            {
+                T.x *= acn_pow( exit_obj->transparency[ 0 ], offs );
+                T.y *= acn_pow( exit_obj->transparency[ 1 ], offs );
+                T.z *= acn_pow( exit_obj->transparency[ 2 ], offs );
+            }
+        }
+
+        if( tsp + 3 > ACN_TASK_STACK ) { cnt->c[ CNT_OVERFLOW ]++; continue; }
+
+        /* fresnel reflection :473-495 */
+        if( fresnel_reflectivity > 0 && intensity >= min_intensity )
+        {
+            V3 out_d;
+            double reflectance = fresnel_reflection( t.d, trans.exit_nor, trix, &out_d ) * fresnel_reflectivity;
+            RayTask c;
+            c.p = pos; c.d = out_d; c.T = T; c.intensity = reflectance * intensity; c.depth = depth - 1; c.kind = 0;
+            tasks[ tsp++ ] = c;
+            intensity *= ( 1.0 - reflectance );
+        }
+
+        /* chromatic reflection :498-523 */
+        if( chromatic_reflectivity > 0 && intensity >= min_intensity )
+        {
+            RayTask c;
+            c.p = pos; c.d = v_reflection( t.d, trans.exit_nor ); c.T = v_mld( T, enter_color );
+            c.intensity = chromatic_reflectivity * intensity; c.depth = depth - 1; c.kind = 0;
+            tasks[ tsp++ ] = c;
+            intensity *= ( 1.0 - chromatic_reflectivity );
+        }
+
+        /* diffuse reflection :526-630 */
+        if( intensity * diffuse_reflectivity >= min_intensity )
+        {
+            ShadeCtx s;
+            s.diffuse_intensity = intensity * diffuse_reflectivity;
+            s.pos = pos;
+            s.surface_d = v_neg( trans.exit_nor );
+            s.theta_i = acn_acos( -v_mlv( t.d, s.surface_d ) );
+            s.ray_projection = v_of_length( v_orthogonal_projection( t.d, s.surface_d ), 1.0 );
+            s.on_a = on_a; s.on_b = on_b;
+            uint64_t rv = v_random_seed( s.pos, 3294479285ull ) + v_random_seed( s.surface_d, 3247146734ull );
+            V3 Tc = v_mld( T, enter_color );
+
+            const acn_node* light = &sc.nodes[ sc.light_root ];
+            for( int i = 0; i < light->child1; i++ )
+            {
+                int light_idx = sc.elems[ light->child0 + i ];
+                const acn_node* light_src = &sc.nodes[ light_idx ];
+                V3 fov_d; double cos_rs;
+                obj_fov_dev( light_src, pos, &fov_d, &cos_rs );
+                M3 src_con = m_transposed( m_con_z( fov_d ) );
+                double cyl_hgt = 1 - cos_rs;
+                uint64_t direct_samples = ( uint64_t )( sc.prm.direct_samples * s.diffuse_intensity );
+                direct_samples = ( direct_samples == 0 ) ? 1 : direct_samples;
+                double sum = 0;
+                for( uint64_t j = 0; j < direct_samples; j++ )
+                {
+                    sum += direct_sample( sc, s, light_idx, light_src, src_con, cyl_hgt, &rv, cnt );
+                }
+                acc_add( acc, Tc, v_mlf( v_mlf( ld3( light_src->color ), sum ), 2.0 * cyl_hgt / direct_samples ) );
+            }
+
+            if( sc.prm.path_samples && depth > 10 )
+            {
+                if( fsp >= ACN_MAX_PATH_LEVELS ) { cnt->c[ CNT_OVERFLOW ]++; }
+                else
+                {
+                    PathFrame& f = frames[ fsp++ ];
+                    f.s = s;
+                    f.out_con = m_transposed( m_con_z( s.surface_d ) );
+                    uint64_t path_samples = ( uint64_t )( sc.prm.path_samples * s.diffuse_intensity );
+                    path_samples = ( path_samples == 0 ) ? 1 : path_samples;
+                    f.T = v_mlf( Tc, 2.0 / path_samples );
+                    f.rv = rv; f.i = 0; f.n = path_samples; f.depth = depth;
+                }
+            }
+            intensity *= ( 1.0 - diffuse_reflectivity );
+        }
+
+        /* refraction :633-653 */
+        if( transparent && intensity >= min_intensity )
+        {
+            RayTask c;
+            c.p = ray_pos( t.p, t.d, offs + 2.0 * F3_EPS );
+            c.d = fresnel_refraction( t.d, trans.exit_nor, trix );
+            c.T = T; c.intensity = intensity; c.depth = depth - 1; c.kind = 0;
+            tasks[ tsp++ ] = c;
+        }
+    }
+}
+
+/* vectors.h:372-384 */
+DEV V3 cl_sat( V3 o, double gamma )
+{
+    double x = acn_pow( o.x, gamma );
+    double y = acn_pow( o.y, gamma );
+    double z = acn_pow( o.z, gamma );
+    x = x > 0.0 ? x < 1.0 ? x : 1.0 : 0.0;
+    y = y > 0.0 ? y < 1.0 ? y : 1.0 : 0.0;
+    z = z > 0.0 ? z < 1.0 ? z : 1.0 : 0.0;
+    return mk( x, y, z );
+}
+
+/* camera ray for a sample position: scene.c:980-990 */
+DEV void camera_ray( const DevScene& sc, double monitor_x, double monitor_y, V3* rp, V3* rd )
+{
+    uint64_t width = sc.prm.image_width, height = sc.prm.image_height;
+    double z = sc.unit_f * ( ( height >> 1 ) - monitor_y );
+    double x = sc.unit_f * ( monitor_x - ( width >> 1 ) );
+    V3 d = v_of_length( mk( x, sc.prm.camera_focal_length, z ), 1.0 );
+    *rp = ld3( sc.prm.camera_position );
+    *rd = m_mlv( sc.camera_rotation, d );
+}
+
+#endif /* ACN_DEVICE_H */

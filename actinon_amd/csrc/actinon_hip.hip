@@ -1,0 +1,472 @@
+/* actinon_hip.hip -- libactinon_hip.so: kernels + the C ABI of include/actinon_hip.h (gfx950 only). */
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "acn_device.h"
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* error plumbing */
+static thread_local std::string g_last_error;
+static int fail( int code, const std::string& msg ) { g_last_error = msg; return code; }
+extern "C" const char* acn_last_error( void ) { return g_last_error.c_str(); }
+
+#define HIP_TRY( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) \
+    return fail( ACN_ERR_DEVICE, std::string( #expr ) + ": " + hipGetErrorString( e_ ) ); } while( 0 )
+
+struct acn_scene_handle
+{
+    int device = 0;
+    DevScene dev{};
+    acn_node* d_nodes = nullptr;
+    int32_t*  d_elems = nullptr;
+    Counters* d_counters = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    uint64_t counters[ 16 ] = { 0 };
+    int max_csg_depth = 0;
+};
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* kernels */
+
+/* camera basis with the oracle's expressions (scene.c:963-973), one lane */
+__global__ void k_camera_setup( DevScene sc, M3* out_rot, double* out_unit_f )
+{
+    uint64_t unit_sz = ( sc.prm.image_height >> 1 );
+    *out_unit_f = 1.0 / unit_sz;
+    V3 ry = v_of_length( ld3( sc.prm.camera_view_direction ), 1 );
+    V3 rz = v_of_length( ld3( sc.prm.camera_top_direction ), 1 );
+    rz = v_von( ry, rz );
+    V3 rx = v_mlx( ry, rz );
+    M3 r; r.x = rx; r.y = ry; r.z = rz;
+    *out_rot = m_transposed( r );
+}
+
+DEV void wave_add_counters( Counters* global, const Counters& mine )
+{
+    for( int k = 0; k < CNT_N; k++ )
+    {
+        unsigned long long v = mine.c[ k ];
+        for( int off = 32; off > 0; off >>= 1 ) v += __shfl_down( v, off, 64 );
+        if( ( threadIdx.x & 63 ) == 0 && v ) atomicAdd( &global->c[ k ], v );
+    }
+}
+
+/* v0: one lane per sample position, serial evaluation (lum_machine_s_func scene.c:956-1013) */
+__global__ __launch_bounds__( 64 )
+void k_render_serial( DevScene sc, const double* __restrict__ pos_xy, size_t first, size_t n, double* __restrict__ out_rgb,
+                      int linear, Counters* counters )
+{
+    size_t i = ( size_t )blockIdx.x * blockDim.x + threadIdx.x;
+    Counters cnt;
+    for( int k = 0; k < CNT_N; k++ ) cnt.c[ k ] = 0;
+    if( i < n )
+    {
+        double mx, my;
+        if( pos_xy ) { mx = pos_xy[ i * 2 ]; my = pos_xy[ i * 2 + 1 ]; }
+        else
+        {
+            size_t pix = first + i;
+            mx = ( double )( pix % sc.prm.image_width ) + 0.5;
+            my = ( double )( pix / sc.prm.image_width ) + 0.5;
+        }
+        RayTask t;
+        camera_ray( sc, mx, my, &t.p, &t.d );
+        t.T = mk( 1, 1, 1 ); t.intensity = 1.0; t.depth = ( int )sc.prm.trace_depth; t.kind = 0;
+        V3 acc = mk( 0, 0, 0 );
+        lum_serial( sc, t, &acc, &cnt );
+        V3 clr = linear ? acc : cl_sat( acc, sc.prm.gamma );
+        out_rgb[ i * 3 + 0 ] = clr.x;
+        out_rgb[ i * 3 + 1 ] = clr.y;
+        out_rgb[ i * 3 + 2 ] = clr.z;
+    }
+    if( counters ) wave_add_counters( counters, cnt );
+}
+
+/* obj_ray_exit + obj_estimate_envelope (objects.c:286-363), one lane */
+__global__ void k_estimate_envelope( DevScene sc, int node, uint64_t samples, uint32_t rseed, double radius_factor,
+                                     V3* scratch, double* out )
+{
+    Counters cnt;
+    for( int k = 0; k < CNT_N; k++ ) cnt.c[ k ] = 0;
+    const acn_node* hdr = &sc.nodes[ node ];
+    uint64_t size = 0;
+    V3 sum = mk( 0, 0, 0 );
+    uint64_t rv = rseed;
+    V3 rp = ld3( hdr->pos );
+    for( uint64_t i = 0; i < samples; i++ )
+    {
+        V3 rd = v_random_sphere_belt( &rv, 1.0 );
+        /* obj_ray_exit */
+        double exit_a = F3_INF;
+        {
+            V3 nor = mk( 0, 0, 0 );
+            double a = obj_ray_hit_dev( sc, node, rp, rd, true, &nor, &cnt );
+            if( a < F3_INF )
+            {
+                V3 lp = rp;
+                double s = 0;
+                while( a < F3_INF )
+                {
+                    a += F3_EPS * 2;
+                    s += a;
+                    lp = ray_pos( lp, rd, a );
+                    a = obj_ray_hit_dev( sc, node, lp, rd, true, &nor, &cnt );
+                }
+                if( v_mlv( nor, rd ) > 0 ) exit_a = s;
+            }
+        }
+        if( exit_a < F3_INF )
+        {
+            V3 pos = ray_pos( rp, rd, exit_a );
+            scratch[ size++ ] = pos;
+            sum = v_add( sum, ray_pos( rp, rd, exit_a ) );
+            rp = v_mlf( sum, ( 1.0 / size ) );
+            rp.x += F3_EPS * f3_rnd0( &rv );
+            rp.y += F3_EPS * f3_rnd0( &rv );
+            rp.z += F3_EPS * f3_rnd0( &rv );
+        }
+    }
+    double radius = F3_MAG;
+    if( size > 0 )
+    {
+        double max_r2 = 0;
+        for( uint64_t i = 0; i < size; i++ )
+        {
+            double r = v_diff_sqr( rp, scratch[ i ] );
+            max_r2 = r > max_r2 ? r : max_r2;
+        }
+        radius = acn_sqrt( max_r2 ) * radius_factor;
+    }
+    out[ 0 ] = rp.x; out[ 1 ] = rp.y; out[ 2 ] = rp.z; out[ 3 ] = radius;
+}
+
+__global__ void k_detmath( int op, const double* x, const double* y, double* out, size_t n )
+{
+    size_t i = ( size_t )blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n ) return;
+    double a = x[ i ], b = y ? y[ i ] : 0.0, r = 0;
+    switch( op )
+    {
+        case 0: r = acn_sin( a ); break;
+        case 1: r = acn_cos( a ); break;
+        case 2: r = acn_tan( a ); break;
+        case 3: r = acn_acos( a ); break;
+        case 4: r = acn_log( a ); break;
+        case 5: r = acn_exp( a ); break;
+        case 6: r = acn_pow( a, b ); break;
+        case 7: r = acn_sqrt( a ); break;
+        case 8: r = a / b; break;
+        case 9: r = ( double )acn_f64_bits( a ); break;
+        case 10: r = acn_frexp_mant( a ); break;
+        default: break;
+    }
+    out[ i ] = r;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* validation: what the reference would abort on, plus the device limits */
+static int csg_depth( const acn_flat_scene* sc, int node, int d, std::string& err )
+{
+    if( d > 4096 ) { err = "cyclic node graph"; return -1; }
+    const acn_node* n = &sc->nodes[ node ];
+    int m = 0;
+    switch( n->type )
+    {
+        case ACN_PAIR_INSIDE: case ACN_PAIR_OUTSIDE:
+        {
+            int a = csg_depth( sc, n->child0, d + 1, err ), b = csg_depth( sc, n->child1, d + 1, err );
+            if( a < 0 || b < 0 ) return -1;
+            m = 1 + ( a > b ? a : b );
+            break;
+        }
+        case ACN_NEG: case ACN_SCALE:
+        {
+            int a = csg_depth( sc, n->child0, d + 1, err );
+            if( a < 0 ) return -1;
+            m = 1 + a;
+            break;
+        }
+        default: break;
+    }
+    return m;
+}
+
+static int compound_depth( const acn_flat_scene* sc, int node, int d, int* max_csg, std::string& err )
+{
+    if( d > 256 ) { err = "compound nesting too deep / cyclic"; return -1; }
+    const acn_node* n = &sc->nodes[ node ];
+    int m = 1;
+    for( int k = 0; k < n->child1; k++ )
+    {
+        int e = sc->elems[ n->child0 + k ];
+        if( sc->nodes[ e ].type == ACN_COMPOUND )
+        {
+            int c = compound_depth( sc, e, d + 1, max_csg, err );
+            if( c < 0 ) return -1;
+            if( c + 1 > m ) m = c + 1;
+        }
+        else
+        {
+            int c = csg_depth( sc, e, 0, err );
+            if( c < 0 ) return -1;
+            if( c > *max_csg ) *max_csg = c;
+        }
+    }
+    return m;
+}
+
+static int validate( const acn_flat_scene* sc, int* max_csg )
+{
+    if( !sc || !sc->nodes ) return fail( ACN_ERR_ARG, "null scene" );
+    if( sc->abi_version != ACN_ABI_VERSION ) return fail( ACN_ERR_ARG, "abi_version mismatch" );
+    if( sc->n_nodes == 0 || sc->light_root < 0 || sc->matter_root < 0 || ( uint32_t )sc->light_root >= sc->n_nodes ||
+        ( uint32_t )sc->matter_root >= sc->n_nodes ) return fail( ACN_ERR_ARG, "bad root index" );
+    if( sc->n_elems && !sc->elems ) return fail( ACN_ERR_ARG, "null elems" );
+    if( sc->params.experimental_level != 0 ) return fail( ACN_ERR_UNSUPPORTED, "Unsupported experimental level" );   /* scene.c:1004-1007 */
+    if( sc->params.image_height < 2 || sc->params.image_width < 1 ) return fail( ACN_ERR_ARG, "image size" );
+    if( sc->params.trace_depth > 10 * ACN_MAX_PATH_LEVELS + 10 ) return fail( ACN_ERR_UNSUPPORTED, "trace_depth exceeds device path-level limit" );
+    for( uint32_t i = 0; i < sc->n_nodes; i++ )
+    {
+        const acn_node* n = &sc->nodes[ i ];
+        if( n->texture != -1 ) return fail( ACN_ERR_UNSUPPORTED, "texture fields are not supported" );
+        switch( n->type )
+        {
+            case ACN_PLANE: case ACN_SPHERE: case ACN_SQUAROID: break;
+            case ACN_DISTANCE:
+                if( n->sdf_kind != ACN_SDF_SPHERE && n->sdf_kind != ACN_SDF_TORUS ) return fail( ACN_ERR_UNSUPPORTED, "unknown distance function" );
+                break;
+            case ACN_PAIR_INSIDE: case ACN_PAIR_OUTSIDE:
+                if( n->child1 < 0 || ( uint32_t )n->child1 >= sc->n_nodes || sc->nodes[ n->child1 ].type == ACN_COMPOUND ) return fail( ACN_ERR_ARG, "bad pair child" );
+                /* fallthrough */
+            case ACN_NEG: case ACN_SCALE:
+                if( n->child0 < 0 || ( uint32_t )n->child0 >= sc->n_nodes || sc->nodes[ n->child0 ].type == ACN_COMPOUND ) return fail( ACN_ERR_ARG, "bad child" );
+                break;
+            case ACN_COMPOUND:
+                if( n->child1 < 0 || n->child0 < 0 || ( uint64_t )n->child0 + ( uint64_t )n->child1 > sc->n_elems ) return fail( ACN_ERR_ARG, "bad compound slice" );
+                for( int k = 0; k < n->child1; k++ )
+                {
+                    int e = sc->elems[ n->child0 + k ];
+                    if( e < 0 || ( uint32_t )e >= sc->n_nodes ) return fail( ACN_ERR_ARG, "bad element index" );
+                }
+                break;
+            default: return fail( ACN_ERR_ARG, "unknown node type" );
+        }
+    }
+    const acn_node* light = &sc->nodes[ sc->light_root ];
+    if( light->type != ACN_COMPOUND || sc->nodes[ sc->matter_root ].type != ACN_COMPOUND ) return fail( ACN_ERR_ARG, "roots must be compounds" );
+    for( int k = 0; k < light->child1; k++ )
+    {
+        int t = sc->nodes[ sc->elems[ light->child0 + k ] ].type;
+        if( t == ACN_COMPOUND ) return fail( ACN_ERR_ARG, "light elements must be objects (scene.c:547)" );
+        if( t != ACN_PLANE && t != ACN_SPHERE && t != ACN_PAIR_INSIDE && t != ACN_PAIR_OUTSIDE )
+            return fail( ACN_ERR_NO_FOV, "light object has no fov-function (objects.c:254-258)" );
+    }
+    std::string err;
+    *max_csg = 0;
+    int dl = compound_depth( sc, sc->light_root, 0, max_csg, err );
+    int dm = dl < 0 ? -1 : compound_depth( sc, sc->matter_root, 0, max_csg, err );
+    if( dl < 0 || dm < 0 ) return fail( ACN_ERR_ARG, err );
+    if( dm > ACN_CMP_MAX_DEPTH || dl > ACN_CMP_MAX_DEPTH ) return fail( ACN_ERR_UNSUPPORTED, "compound nesting exceeds device limit" );
+    if( *max_csg > ACN_CSG_MAX_DEPTH ) return fail( ACN_ERR_UNSUPPORTED, "CSG nesting exceeds device limit" );
+    return ACN_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* ABI */
+extern "C" int acn_device_count( void )
+{
+    int n = 0;
+    if( hipGetDeviceCount( &n ) != hipSuccess ) return 0;
+    return n;
+}
+
+extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_scene_handle** out )
+{
+    if( !out ) return fail( ACN_ERR_ARG, "null out" );
+    *out = nullptr;
+    int max_csg = 0;
+    int st = validate( scene, &max_csg );
+    if( st != ACN_OK ) return st;
+    int ndev = acn_device_count();
+    if( ndev <= 0 ) return fail( ACN_ERR_DEVICE, "no HIP device (libactinon_hip has no CPU fallback)" );
+    if( device < 0 || device >= ndev ) return fail( ACN_ERR_ARG, "bad device index" );
+    HIP_TRY( hipSetDevice( device ) );
+    acn_scene_handle* h = new acn_scene_handle();
+    h->device = device;
+    h->max_csg_depth = max_csg;
+    auto bail = [ & ]( int code ) { acn_scene_free( h ); return code; };
+#define HIP_TRY_H( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) \
+    return bail( fail( ACN_ERR_DEVICE, std::string( #expr ) + ": " + hipGetErrorString( e_ ) ) ); } while( 0 )
+    HIP_TRY_H( hipStreamCreate( &h->stream ) );
+    HIP_TRY_H( hipEventCreate( &h->ev0 ) );
+    HIP_TRY_H( hipEventCreate( &h->ev1 ) );
+    HIP_TRY_H( hipMalloc( &h->d_nodes, sizeof( acn_node ) * scene->n_nodes ) );
+    HIP_TRY_H( hipMalloc( &h->d_elems, sizeof( int32_t ) * ( scene->n_elems ? scene->n_elems : 1 ) ) );
+    HIP_TRY_H( hipMalloc( &h->d_counters, sizeof( Counters ) ) );
+    HIP_TRY_H( hipMemcpy( h->d_nodes, scene->nodes, sizeof( acn_node ) * scene->n_nodes, hipMemcpyHostToDevice ) );
+    if( scene->n_elems ) HIP_TRY_H( hipMemcpy( h->d_elems, scene->elems, sizeof( int32_t ) * scene->n_elems, hipMemcpyHostToDevice ) );
+    h->dev.nodes = h->d_nodes;
+    h->dev.elems = h->d_elems;
+    h->dev.light_root = scene->light_root;
+    h->dev.matter_root = scene->matter_root;
+    h->dev.n_nodes = scene->n_nodes;
+    h->dev.n_elems = scene->n_elems;
+    h->dev.prm = scene->params;
+    /* camera basis on the device so that it shares the device's arithmetic */
+    {
+        M3* d_rot = nullptr; double* d_uf = nullptr;
+        HIP_TRY_H( hipMalloc( &d_rot, sizeof( M3 ) ) );
+        HIP_TRY_H( hipMalloc( &d_uf, sizeof( double ) ) );
+        hipLaunchKernelGGL( k_camera_setup, dim3( 1 ), dim3( 1 ), 0, h->stream, h->dev, d_rot, d_uf );
+        HIP_TRY_H( hipGetLastError() );
+        HIP_TRY_H( hipStreamSynchronize( h->stream ) );
+        HIP_TRY_H( hipMemcpy( &h->dev.camera_rotation, d_rot, sizeof( M3 ), hipMemcpyDeviceToHost ) );
+        HIP_TRY_H( hipMemcpy( &h->dev.unit_f, d_uf, sizeof( double ), hipMemcpyDeviceToHost ) );
+        hipFree( d_rot ); hipFree( d_uf );
+    }
+    *out = h;
+    return ACN_OK;
+}
+
+extern "C" void acn_scene_free( acn_scene_handle* h )
+{
+    if( !h ) return;
+    hipSetDevice( h->device );
+    if( h->d_nodes ) hipFree( h->d_nodes );
+    if( h->d_elems ) hipFree( h->d_elems );
+    if( h->d_counters ) hipFree( h->d_counters );
+    if( h->ev0 ) hipEventDestroy( h->ev0 );
+    if( h->ev1 ) hipEventDestroy( h->ev1 );
+    if( h->stream ) hipStreamDestroy( h->stream );
+    delete h;
+}
+
+static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t first, size_t n, double* d_out_rgb,
+                          const acn_render_opts* opts, hipStream_t stream )
+{
+    if( opts && opts->cancel && *opts->cancel ) return fail( ACN_ERR_CANCELLED, "cancelled" );
+    if( n == 0 ) return ACN_OK;
+    int linear = ( opts && ( opts->flags & ACN_OPT_LINEAR_OUT ) ) ? 1 : 0;
+    HIP_TRY( hipMemsetAsync( h->d_counters, 0, sizeof( Counters ), stream ) );
+    HIP_TRY( hipEventRecord( h->ev0, stream ) );
+    size_t blocks = ( n + 63 ) / 64;
+    hipLaunchKernelGGL( k_render_serial, dim3( ( unsigned )blocks ), dim3( 64 ), 0, stream,
+                        h->dev, d_pos_xy, first, n, d_out_rgb, linear, h->d_counters );
+    HIP_TRY( hipGetLastError() );
+    HIP_TRY( hipEventRecord( h->ev1, stream ) );
+    h->timed = true;
+    return ACN_OK;
+}
+
+extern "C" int acn_render_positions_dev( acn_scene_handle* h, const void* d_pos_xy, size_t n, void* d_out_rgb,
+                                         const acn_render_opts* opts )
+{
+    if( !h || ( n && ( !d_pos_xy || !d_out_rgb ) ) ) return fail( ACN_ERR_ARG, "null argument" );
+    HIP_TRY( hipSetDevice( h->device ) );
+    hipStream_t stream = ( opts && opts->stream ) ? ( hipStream_t )opts->stream : h->stream;
+    int st = launch_render( h, ( const double* )d_pos_xy, 0, n, ( double* )d_out_rgb, opts, stream );
+    if( st != ACN_OK ) return st;
+    if( !( opts && opts->stream ) ) HIP_TRY( hipStreamSynchronize( stream ) );
+    return ACN_OK;
+}
+
+extern "C" int acn_render_main_pass_dev( acn_scene_handle* h, size_t first, size_t count, void* d_out_rgb,
+                                         const acn_render_opts* opts )
+{
+    if( !h || ( count && !d_out_rgb ) ) return fail( ACN_ERR_ARG, "null argument" );
+    if( first + count > h->dev.prm.image_width * h->dev.prm.image_height ) return fail( ACN_ERR_ARG, "pixel range outside the image" );
+    HIP_TRY( hipSetDevice( h->device ) );
+    hipStream_t stream = ( opts && opts->stream ) ? ( hipStream_t )opts->stream : h->stream;
+    int st = launch_render( h, nullptr, first, count, ( double* )d_out_rgb, opts, stream );
+    if( st != ACN_OK ) return st;
+    if( !( opts && opts->stream ) ) HIP_TRY( hipStreamSynchronize( stream ) );
+    return ACN_OK;
+}
+
+extern "C" int acn_render_positions( acn_scene_handle* h, const double* pos_xy, size_t n, double* out_rgb,
+                                     const acn_render_opts* opts )
+{
+    if( !h || ( n && ( !pos_xy || !out_rgb ) ) ) return fail( ACN_ERR_ARG, "null argument" );
+    if( n == 0 ) return ACN_OK;
+    HIP_TRY( hipSetDevice( h->device ) );
+    double* d_pos = nullptr; double* d_out = nullptr;
+    HIP_TRY( hipMalloc( &d_pos, sizeof( double ) * 2 * n ) );
+    hipError_t e = hipMalloc( &d_out, sizeof( double ) * 3 * n );
+    if( e != hipSuccess ) { hipFree( d_pos ); return fail( ACN_ERR_DEVICE, hipGetErrorString( e ) ); }
+    int st = ACN_OK;
+    acn_render_opts o{};
+    if( opts ) o = *opts;
+    o.stream = nullptr;
+    if( hipMemcpy( d_pos, pos_xy, sizeof( double ) * 2 * n, hipMemcpyHostToDevice ) != hipSuccess ) st = fail( ACN_ERR_DEVICE, "H2D copy failed" );
+    if( st == ACN_OK ) st = acn_render_positions_dev( h, d_pos, n, d_out, &o );
+    if( st == ACN_OK && hipMemcpy( out_rgb, d_out, sizeof( double ) * 3 * n, hipMemcpyDeviceToHost ) != hipSuccess ) st = fail( ACN_ERR_DEVICE, "D2H copy failed" );
+    hipFree( d_pos ); hipFree( d_out );
+    return st;
+}
+
+extern "C" int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms )
+{
+    if( !h || !trace_ms || !h->timed ) return fail( ACN_ERR_ARG, "no timed launch" );
+    HIP_TRY( hipSetDevice( h->device ) );
+    HIP_TRY( hipEventSynchronize( h->ev1 ) );
+    float ms = 0;
+    HIP_TRY( hipEventElapsedTime( &ms, h->ev0, h->ev1 ) );
+    *trace_ms = ms;
+    return ACN_OK;
+}
+
+extern "C" int acn_last_counters( acn_scene_handle* h, uint64_t* out, int n )
+{
+    if( !h || !out || n < 0 || n > 16 ) return fail( ACN_ERR_ARG, "bad argument" );
+    HIP_TRY( hipSetDevice( h->device ) );
+    Counters c;
+    HIP_TRY( hipMemcpy( &c, h->d_counters, sizeof( c ), hipMemcpyDeviceToHost ) );
+    for( int k = 0; k < n; k++ ) out[ k ] = k < CNT_N ? c.c[ k ] : 0;
+    return ACN_OK;
+}
+
+extern "C" int acn_estimate_envelope( acn_scene_handle* h, int32_t node, uint64_t samples, uint32_t rseed,
+                                      double radius_factor, double* out )
+{
+    if( !h || !out || node < 0 || ( uint32_t )node >= h->dev.n_nodes ) return fail( ACN_ERR_ARG, "bad argument" );
+    HIP_TRY( hipSetDevice( h->device ) );
+    V3* d_scratch = nullptr; double* d_out = nullptr;
+    HIP_TRY( hipMalloc( &d_scratch, sizeof( V3 ) * ( samples ? samples : 1 ) ) );
+    HIP_TRY( hipMalloc( &d_out, sizeof( double ) * 4 ) );
+    hipLaunchKernelGGL( k_estimate_envelope, dim3( 1 ), dim3( 1 ), 0, h->stream, h->dev, node, samples, rseed, radius_factor, d_scratch, d_out );
+    hipError_t e = hipGetLastError();
+    if( e == hipSuccess ) e = hipStreamSynchronize( h->stream );
+    if( e == hipSuccess ) e = hipMemcpy( out, d_out, sizeof( double ) * 4, hipMemcpyDeviceToHost );
+    hipFree( d_scratch ); hipFree( d_out );
+    if( e != hipSuccess ) return fail( ACN_ERR_DEVICE, hipGetErrorString( e ) );
+    return ACN_OK;
+}
+
+extern "C" int acn_detmath_eval( int device, int op, const double* x, const double* y, double* out, size_t n )
+{
+    if( !x || !out ) return fail( ACN_ERR_ARG, "null argument" );
+    if( acn_device_count() <= 0 ) return fail( ACN_ERR_DEVICE, "no HIP device" );
+    HIP_TRY( hipSetDevice( device ) );
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    HIP_TRY( hipMalloc( &dx, sizeof( double ) * n ) );
+    HIP_TRY( hipMalloc( &dout, sizeof( double ) * n ) );
+    HIP_TRY( hipMemcpy( dx, x, sizeof( double ) * n, hipMemcpyHostToDevice ) );
+    if( y )
+    {
+        HIP_TRY( hipMalloc( &dy, sizeof( double ) * n ) );
+        HIP_TRY( hipMemcpy( dy, y, sizeof( double ) * n, hipMemcpyHostToDevice ) );
+    }
+    hipLaunchKernelGGL( k_detmath, dim3( ( unsigned )( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, 0, op, dx, dy, dout, n );
+    HIP_TRY( hipGetLastError() );
+    HIP_TRY( hipDeviceSynchronize() );
+    HIP_TRY( hipMemcpy( out, dout, sizeof( double ) * n, hipMemcpyDeviceToHost ) );
+    hipFree( dx ); hipFree( dout ); if( dy ) hipFree( dy );
+    return ACN_OK;
+}

@@ -1,0 +1,206 @@
+/* acn_driver.c -- host render driver: the caller side of the seam (see include/acn_scene.h).
+ *
+ *   acn_lum_machine_s_run          <- lum_machine_s_run            src/scene.c:1017-1028 (now: one GPU call)
+ *   acn_scene_s_create_image_file  <- scene_s_create_image_file    src/scene.c:1032-1165
+ *   lum_image accumulation         <- lum_image_s_*                src/scene.c:744-885
+ *   acn_write_pnm / acn_cps_from_cl<- image_cps_s_write_pnm, cps_from_cl   src/scene.c:76-82,122-137
+ *
+ * Not carried over (out of scope): SIGINT soft stop and the beth-serialised recovery file.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "acn_scene.h"
+
+int acn_scene_s_overwrite_output_files_g = 0;
+
+uint32_t acn_cps_from_cl( const double* cl )
+{
+    uint8_t r = cl[ 0 ] > 0.0 ? cl[ 0 ] < 1.0 ? ( uint8_t )( cl[ 0 ] * 256 ) : 255 : 0;
+    uint8_t g = cl[ 1 ] > 0.0 ? cl[ 1 ] < 1.0 ? ( uint8_t )( cl[ 1 ] * 256 ) : 255 : 0;
+    uint8_t b = cl[ 2 ] > 0.0 ? cl[ 2 ] < 1.0 ? ( uint8_t )( cl[ 2 ] * 256 ) : 255 : 0;
+    return ( uint32_t )r | ( ( uint32_t )g ) << 8 | ( ( uint32_t )b ) << 16;
+}
+
+int acn_write_pnm( const char* file, const double* rgb, size_t w, size_t h )
+{
+    FILE* f = fopen( file, "wb" );
+    if( !f ) return ACN_ERR_ARG;
+    fprintf( f, "P6\n%zu %zu\n255\n", w, h );
+    uint8_t* row = malloc( w * 3 );
+    for( size_t j = 0; j < h; j++ )
+    {
+        for( size_t i = 0; i < w; i++ )
+        {
+            uint32_t v = acn_cps_from_cl( rgb + ( j * w + i ) * 3 );
+            row[ i * 3 + 0 ] = ( uint8_t )v;
+            row[ i * 3 + 1 ] = ( uint8_t )( v >> 8 );
+            row[ i * 3 + 2 ] = ( uint8_t )( v >> 16 );
+        }
+        fwrite( row, 1, w * 3, f );
+    }
+    free( row );
+    fclose( f );
+    return ACN_OK;
+}
+
+static int run_on_handle( acn_scene_handle* h, acn_lum* lum_arr, size_t n )
+{
+    if( n == 0 ) return ACN_OK;
+    double* pos = malloc( sizeof( double ) * 2 * n );
+    double* clr = malloc( sizeof( double ) * 3 * n );
+    for( size_t i = 0; i < n; i++ ) { pos[ i * 2 ] = lum_arr[ i ].pos_x; pos[ i * 2 + 1 ] = lum_arr[ i ].pos_y; }
+    int st = acn_render_positions( h, pos, n, clr, NULL );
+    if( st == ACN_OK )
+    {
+        for( size_t i = 0; i < n; i++ ) memcpy( lum_arr[ i ].clr, clr + i * 3, sizeof( double ) * 3 );
+    }
+    free( pos );
+    free( clr );
+    return st;
+}
+
+int acn_lum_machine_s_run( const acn_scene* scene, acn_lum* lum_arr, size_t n )
+{
+    acn_flat_scene f;
+    int st = acn_scene_s_flatten( scene, &f );
+    if( st != ACN_OK ) return st;
+    acn_scene_handle* h = NULL;
+    st = acn_scene_upload( &f, scene->device, &h );
+    if( st == ACN_OK ) st = run_on_handle( h, lum_arr, n );
+    if( h ) acn_scene_free( h );
+    acn_flat_scene_free( &f );
+    return st;
+}
+
+/* lum_image_s scene.c:744-862 */
+typedef struct { size_t width, height; acn_lum* data; } lum_image;
+
+static void lum_image_push( lum_image* o, const acn_lum* lum )   /* scene.c:804-813 */
+{
+    int32_t x = ( int32_t )( lum->pos_x / lum->weight );
+    int32_t y = ( int32_t )( lum->pos_y / lum->weight );
+    if( x >= 0 && ( size_t )x < o->width && y >= 0 && ( size_t )y < o->height )
+    {
+        acn_lum* d = &o->data[ ( size_t )y * o->width + x ];
+        d->pos_x += lum->pos_x; d->pos_y += lum->pos_y;
+        d->clr[ 0 ] += lum->clr[ 0 ]; d->clr[ 1 ] += lum->clr[ 1 ]; d->clr[ 2 ] += lum->clr[ 2 ];
+        d->weight += lum->weight;
+    }
+}
+
+static void lum_image_avg_clr( const lum_image* o, int64_t x, int64_t y, double* clr )   /* scene.c:824-835 */
+{
+    acn_lum lum;
+    memset( &lum, 0, sizeof( lum ) );
+    if( x >= 0 && ( size_t )x < o->width && y >= 0 && ( size_t )y < o->height ) lum = o->data[ ( size_t )y * o->width + x ];
+    double f = ( lum.weight > 0 ) ? 1.0 / lum.weight : 1.0;
+    clr[ 0 ] = lum.clr[ 0 ] * f; clr[ 1 ] = lum.clr[ 1 ] * f; clr[ 2 ] = lum.clr[ 2 ] * f;
+}
+
+static double lum_image_clr_dev( const lum_image* o, const double* ref, int64_t x, int64_t y )   /* scene.c:839-844 */
+{
+    if( x < 0 || ( size_t )x >= o->width ) return 0;
+    if( y < 0 || ( size_t )y >= o->height ) return 0;
+    double c[ 3 ];
+    lum_image_avg_clr( o, x, y, c );
+    double dx = ref[ 0 ] - c[ 0 ], dy = ref[ 1 ] - c[ 1 ], dz = ref[ 2 ] - c[ 2 ];
+    return ( dx * dx ) + ( dy * dy ) + ( dz * dz );
+}
+
+static double lum_image_sqr_grad( const lum_image* o, int64_t x, int64_t y )   /* scene.c:848-862 */
+{
+    double g0 = 0, g1;
+    double v[ 3 ];
+    lum_image_avg_clr( o, x, y, v );
+    static const int dx[ 8 ] = { -1, -1, -1, 0, 0, 1, 1, 1 };
+    static const int dy[ 8 ] = { -1, 0, 1, -1, 1, -1, 0, 1 };
+    for( int k = 0; k < 8; k++ )
+    {
+        g1 = lum_image_clr_dev( o, v, x + dx[ k ], y + dy[ k ] );
+        g0 = g1 > g0 ? g1 : g0;
+    }
+    return g0;
+}
+
+static int lum_image_write( const lum_image* o, const char* file )   /* scene.c:866-885 */
+{
+    double* rgb = malloc( sizeof( double ) * 3 * o->width * o->height );
+    for( size_t j = 0; j < o->height; j++ )
+        for( size_t i = 0; i < o->width; i++ )
+            lum_image_avg_clr( o, ( int64_t )i, ( int64_t )j, rgb + ( j * o->width + i ) * 3 );
+    int st = acn_write_pnm( file, rgb, o->width, o->height );
+    free( rgb );
+    return st;
+}
+
+int acn_scene_s_create_image_file( acn_scene* o, const char* file )
+{
+    if( !acn_scene_s_overwrite_output_files_g )
+    {
+        FILE* f = fopen( file, "rb" );
+        if( f ) { fclose( f ); fprintf( stderr, "Image file '%s' exists (set acn_scene_s_overwrite_output_files_g).\n", file ); return ACN_ERR_ARG; }
+    }
+    printf( "Number of objects: %zu\n", acn_scene_s_objects( o ) );
+
+    acn_flat_scene flat;
+    int st = acn_scene_s_flatten( o, &flat );
+    if( st != ACN_OK ) return st;
+    acn_scene_handle* h = NULL;
+    st = acn_scene_upload( &flat, o->device, &h );
+    if( st != ACN_OK ) { acn_flat_scene_free( &flat ); return st; }
+
+    size_t w = o->prm.image_width, hgt = o->prm.image_height;
+    lum_image img = { w, hgt, calloc( w * hgt, sizeof( acn_lum ) ) };
+    uint64_t rval = 21943294;   /* scene.c:799 */
+    double sqr_gradient_threshold = o->gradient_threshold * o->gradient_threshold;
+
+    acn_lum* arr = NULL;
+    size_t arr_space = 0;
+    printf( "Rendering ...\n" );
+    for( uint64_t cycle = 0; cycle <= o->gradient_cycles && st == ACN_OK; cycle++ )
+    {
+        size_t n = 0;
+#define PUSH_POS( px, py ) do { \
+            if( n == arr_space ) { arr_space = arr_space ? arr_space * 2 : 256; arr = realloc( arr, sizeof( acn_lum ) * arr_space ); } \
+            memset( &arr[ n ], 0, sizeof( acn_lum ) ); arr[ n ].pos_x = ( px ); arr[ n ].pos_y = ( py ); arr[ n ].weight = 1.0; n++; } while( 0 )
+        if( cycle == 0 )
+        {
+            printf( "\n\tmain image: " );
+            for( size_t j = 0; j < hgt; j++ ) for( size_t i = 0; i < w; i++ ) PUSH_POS( i + 0.5, j + 0.5 );
+        }
+        else
+        {
+            printf( "\n\tgradient pass %3llu: ", ( unsigned long long )cycle );
+            for( int64_t j = 0; j < ( int64_t )hgt; j++ )
+            {
+                for( int64_t i = 0; i < ( int64_t )w; i++ )
+                {
+                    if( lum_image_sqr_grad( &img, i, j ) > sqr_gradient_threshold )
+                    {
+                        for( uint64_t k = 0; k < o->gradient_samples; k++ )
+                        {
+                            /* f3_rnd1 vectors.h:48 with the declared lcg00 */
+                            double dx = ( double )( rval = rval * ACN_LCG00_A + ACN_LCG00_C ) * ( 1.0 / 0xFFFFFFFFFFFFFFFFull );
+                            double dy = ( double )( rval = rval * ACN_LCG00_A + ACN_LCG00_C ) * ( 1.0 / 0xFFFFFFFFFFFFFFFFull );
+                            PUSH_POS( i + dx, j + dy );
+                        }
+                    }
+                }
+            }
+        }
+#undef PUSH_POS
+        fflush( stdout );
+        st = run_on_handle( h, arr, n );
+        if( st != ACN_OK ) break;
+        for( size_t i = 0; i < n; i++ ) lum_image_push( &img, &arr[ i ] );
+        st = lum_image_write( &img, file );
+    }
+    printf( "\n" );
+    free( arr );
+    free( img.data );
+    acn_scene_free( h );
+    acn_flat_scene_free( &flat );
+    return st;
+}

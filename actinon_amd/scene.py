@@ -1,0 +1,212 @@
+"""Python face of the host-side scene model (libactinon_host.so) and of the render seam (libactinon_hip.so).
+
+Everything here is plumbing over the C ABI: scene assembly happens in C (actinon_amd/host/*.c), rendering in the
+HIP library.  Mirrors, for this path, what the reference's script interpreter does with scene_s
+(/root/reference/src/scene.c:293-331): set fields, push objects, create_image."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from ._lib import hip, host, check, AcnError
+
+
+def v3(x, y=None, z=None):
+    if y is None:
+        x, y, z = x
+    return abi.V3(float(x), float(y), float(z))
+
+
+class Flat:
+    """An acn_flat_scene owned by Python (arrays allocated by libactinon_host, freed on __del__)."""
+
+    def __init__(self):
+        self.c = abi.FlatScene()
+        self._owned = False
+
+    def __del__(self):
+        if getattr(self, "_owned", False):
+            host.acn_flat_scene_free(C.byref(self.c))
+            self._owned = False
+
+    @property
+    def n_nodes(self):
+        return self.c.n_nodes
+
+    @property
+    def params(self):
+        return self.c.params
+
+    def node(self, i):
+        return self.c.nodes[i]
+
+    def elems_of(self, compound_index):
+        n = self.c.nodes[compound_index]
+        return [self.c.elems[n.child0 + k] for k in range(n.child1)]
+
+    def nodes_bytes(self):
+        return C.string_at(self.c.nodes, C.sizeof(abi.Node) * self.c.n_nodes)
+
+
+class Scene:
+    """Wraps an acn_scene* (scene_s counterpart)."""
+
+    BUILDERS = {"primitives": "acn_scene_primitives", "wine_glass": "acn_scene_wine_glass",
+                "diamond": "acn_scene_diamond"}
+
+    def __init__(self, ptr=None):
+        if ptr is None:
+            ptr = C.cast(host.acn_scene_s_create(), C.c_void_p).value
+        if not ptr:
+            raise AcnError(abi.ACN_ERR_ARG, "scene construction failed")
+        self.ptr = ptr
+        self.s = C.cast(ptr, C.POINTER(abi.SceneStruct)).contents
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            host.acn_scene_s_discard(self.ptr)
+            self.ptr = None
+
+    @classmethod
+    def build(cls, name, **overrides):
+        """name: primitives | wine_glass | diamond | many_spheres[:levels[:exact]]; overrides set acn_params fields."""
+        if name.startswith("many_spheres"):
+            parts = name.split(":")
+            levels = int(parts[1]) if len(parts) > 1 else 5
+            exact = int(parts[2]) if len(parts) > 2 else 0
+            ptr = host.acn_scene_many_spheres(levels, exact)
+        else:
+            ptr = getattr(host, cls.BUILDERS[name])()
+        sc = cls(ptr)
+        sc.set(**overrides)
+        return sc
+
+    def set(self, **kw):
+        for k, v in kw.items():
+            if hasattr(self.s.prm, k):
+                cur = getattr(self.s.prm, k)
+                if hasattr(cur, "__len__"):
+                    for i in range(len(cur)):
+                        cur[i] = float(v[i])
+                else:
+                    setattr(self.s.prm, k, v)
+            elif hasattr(self.s, k):
+                setattr(self.s, k, v)
+            else:
+                raise AttributeError(f"scene_s has no member '{k}'")
+        return self
+
+    @property
+    def prm(self):
+        return self.s.prm
+
+    def objects(self):
+        return host.acn_scene_s_objects(self.ptr)
+
+    def clear(self):
+        host.acn_scene_s_clear(self.ptr)
+
+    def push(self, obj_ptr):
+        return host.acn_scene_s_push(self.ptr, obj_ptr)
+
+    def flatten(self):
+        f = Flat()
+        check(host.acn_scene_s_flatten(self.ptr, C.byref(f.c)), "acn_scene_s_flatten")
+        f._owned = True
+        return f
+
+    def create_image_file(self, path, overwrite=True):
+        C.c_int.in_dll(host, "acn_scene_s_overwrite_output_files_g").value = 1 if overwrite else 0
+        check(host.acn_scene_s_create_image_file(self.ptr, path.encode()), "acn_scene_s_create_image_file")
+
+
+class Handle:
+    """A flattened scene resident on one GPU (acn_scene_handle)."""
+
+    def __init__(self, flat, device=0):
+        self.flat = flat
+        self.device = device
+        self.h = C.c_void_p()
+        check(hip.acn_scene_upload(C.byref(flat.c), device, C.byref(self.h)), "acn_scene_upload")
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            hip.acn_scene_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        self.close()
+
+    def _opts(self, linear, stream):
+        o = abi.RenderOpts()
+        o.flags = abi.ACN_OPT_LINEAR_OUT if linear else 0
+        o.stream = stream
+        return o
+
+    def render_positions(self, pos_xy, linear=False):
+        """lum_machine_s_run on host arrays: pos_xy [n,2] float64 -> rgb [n,3] float64."""
+        pos = np.ascontiguousarray(pos_xy, dtype=np.float64).reshape(-1, 2)
+        out = np.empty((pos.shape[0], 3), dtype=np.float64)
+        o = self._opts(linear, None)
+        check(hip.acn_render_positions(self.h, pos.ctypes.data, pos.shape[0], out.ctypes.data, C.byref(o)),
+              "acn_render_positions")
+        return out
+
+    def render_positions_dev(self, d_pos_ptr, n, d_out_ptr, linear=False, stream=None):
+        o = self._opts(linear, stream)
+        check(hip.acn_render_positions_dev(self.h, d_pos_ptr, n, d_out_ptr, C.byref(o)), "acn_render_positions_dev")
+
+    def render_main_pass_dev(self, first, count, d_out_ptr, linear=False, stream=None):
+        o = self._opts(linear, stream)
+        check(hip.acn_render_main_pass_dev(self.h, first, count, d_out_ptr, C.byref(o)), "acn_render_main_pass_dev")
+
+    def last_kernel_ms(self):
+        ms = C.c_double()
+        check(hip.acn_last_kernel_ms(self.h, C.byref(ms)), "acn_last_kernel_ms")
+        return ms.value
+
+    def last_counters(self):
+        names = ["trans_rays", "shadow_rays", "obj_hits", "lum_calls", "cap_samples", "side_calls", "sdf_evals",
+                 "overflows"]
+        buf = (C.c_uint64 * 8)()
+        check(hip.acn_last_counters(self.h, buf, 8), "acn_last_counters")
+        return dict(zip(names, [int(v) for v in buf]))
+
+    def estimate_envelope(self, node, samples=1000, rseed=123, radius_factor=1.1):
+        out = (C.c_double * 4)()
+        check(hip.acn_estimate_envelope(self.h, node, samples, rseed, radius_factor, out), "acn_estimate_envelope")
+        return list(out)
+
+
+def main_pass_positions(width, height, first=0, count=None):
+    """Pixel centres of the main pass, row-major (scene.c:1110-1119)."""
+    n = width * height if count is None else count
+    idx = np.arange(first, first + n)
+    pos = np.empty((n, 2), dtype=np.float64)
+    pos[:, 0] = (idx % width) + 0.5
+    pos[:, 1] = (idx // width) + 0.5
+    return pos
+
+
+def cps_from_cl(rgb):
+    """8-bit quantisation of scene.c:76-82 on an [...,3] array."""
+    rgb = np.asarray(rgb)
+    q = np.where(rgb > 0.0, np.where(rgb < 1.0, (rgb * 256).astype(np.int64), 255), 0)
+    return q.astype(np.uint8)
+
+
+def device_count():
+    return hip.acn_device_count()
+
+
+def detmath_eval(op, x, y=None, device=0):
+    ops = {"sin": 0, "cos": 1, "tan": 2, "acos": 3, "log": 4, "exp": 5, "pow": 6, "sqrt": 7, "div": 8, "u64_to_f64": 9,
+           "frexp_mant": 10}
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    yp = None
+    if y is not None:
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        yp = y.ctypes.data
+    check(hip.acn_detmath_eval(device, ops[op], x.ctypes.data, yp, out.ctypes.data, x.size), "acn_detmath_eval")
+    return out

@@ -1,0 +1,46 @@
+"""Generates tests/golden/ref_image_blocks.json from the reference's own shipped renders.
+
+Run in the build container only (reads /root/reference/image/*.png; that tree does not exist on the GPU box):
+    python tests/golden/make_ref_image_blocks.py
+
+The reference has no tests or golden vectors; its rendered example images are the only outputs of
+the reference that exist.  They were produced at each script's own settings (incl. adaptive anti-aliasing and the
+unknown beth LCG), so they pin the path statistically, not per pixel: we store BxB block means of the 8-bit
+images (B = 16 pixels) as data, not the images themselves.  Images are CC-BY-SA 4.0 (reference README.md:132),
+(c) Johannes B. Steffens; this derived table inherits that licence.
+"""
+import json
+import os
+
+import numpy as np
+from PIL import Image
+
+REF = "/root/reference/image"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_image_blocks.json")
+BLOCK = 16
+IMAGES = {"primitives": "primitives.acn.png", "wine_glass": "wine_glass.acn.png", "diamond": "diamond.acn.png",
+          "many_spheres": "many_spheres.acn.png"}
+
+
+def block_means(img, b):
+    h, w, _ = img.shape
+    hb, wb = h // b, w // b
+    v = img[:hb * b, :wb * b].reshape(hb, b, wb, b, 3).astype(np.float64)
+    return v.mean(axis=(1, 3))
+
+
+def main():
+    out = {"block": BLOCK, "unit": "8-bit value (0..255)", "source": "johsteffens/actinon image/*.png (CC-BY-SA 4.0)",
+           "images": {}}
+    for name, fn in IMAGES.items():
+        img = np.asarray(Image.open(os.path.join(REF, fn)).convert("RGB"))
+        bm = block_means(img, BLOCK)
+        out["images"][name] = {"file": fn, "width": int(img.shape[1]), "height": int(img.shape[0]),
+                               "block_means": np.round(bm, 3).tolist()}
+    with open(OUT, "w") as f:
+        json.dump(out, f)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()
