@@ -68,43 +68,43 @@ class Oracle:
         return np.ascontiguousarray(v, dtype=np.float64)
 
     def sphere_ray_hit(self, pos, r, rp, rd):
-        nor = np.zeros(3)
-        a = self.lib.acn_oracle_sphere_ray_hit(self._a(pos).ctypes.data, r, self._a(rp).ctypes.data,
-                                               self._a(rd).ctypes.data, nor.ctypes.data)
+        pos, rp, rd, nor = self._a(pos), self._a(rp), self._a(rd), np.zeros(3)
+        a = self.lib.acn_oracle_sphere_ray_hit(pos.ctypes.data, r, rp.ctypes.data, rd.ctypes.data, nor.ctypes.data)
         return a, nor
 
     def plane_ray_hit(self, pos, nor, rp, rd):
-        return self.lib.acn_oracle_plane_ray_hit(self._a(pos).ctypes.data, self._a(nor).ctypes.data,
-                                                 self._a(rp).ctypes.data, self._a(rd).ctypes.data)
+        pos, nor, rp, rd = self._a(pos), self._a(nor), self._a(rp), self._a(rd)
+        return self.lib.acn_oracle_plane_ray_hit(pos.ctypes.data, nor.ctypes.data, rp.ctypes.data, rd.ctypes.data)
 
     def fresnel_reflection(self, d, n, trix):
-        out = np.zeros(3)
-        r = self.lib.acn_oracle_fresnel_reflection(self._a(d).ctypes.data, self._a(n).ctypes.data, trix, out.ctypes.data)
+        d, n, out = self._a(d), self._a(n), np.zeros(3)
+        r = self.lib.acn_oracle_fresnel_reflection(d.ctypes.data, n.ctypes.data, trix, out.ctypes.data)
         return r, out
 
     def fresnel_refraction(self, d, n, trix):
-        out = np.zeros(3)
-        self.lib.acn_oracle_fresnel_refraction(self._a(d).ctypes.data, self._a(n).ctypes.data, trix, out.ctypes.data)
+        d, n, out = self._a(d), self._a(n), np.zeros(3)
+        self.lib.acn_oracle_fresnel_refraction(d.ctypes.data, n.ctypes.data, trix, out.ctypes.data)
         return out
 
     def obj_ray_hit(self, flat, node, rp, rd):
-        nor = np.zeros(3)
-        a = self.lib.acn_oracle_obj_ray_hit(C.addressof(flat.c), node, self._a(rp).ctypes.data, self._a(rd).ctypes.data,
-                                            nor.ctypes.data)
+        rp, rd, nor = self._a(rp), self._a(rd), np.zeros(3)
+        a = self.lib.acn_oracle_obj_ray_hit(C.addressof(flat.c), node, rp.ctypes.data, rd.ctypes.data, nor.ctypes.data)
         return a, nor
 
     def obj_side(self, flat, node, pos):
-        return self.lib.acn_oracle_obj_side(C.addressof(flat.c), node, self._a(pos).ctypes.data)
+        pos = self._a(pos)
+        return self.lib.acn_oracle_obj_side(C.addressof(flat.c), node, pos.ctypes.data)
 
     def trans_hit(self, flat, rp, rd):
-        nor = np.zeros(3)
+        rp, rd, nor = self._a(rp), self._a(rd), np.zeros(3)
         ex, en = C.c_int32(-1), C.c_int32(-1)
-        a = self.lib.acn_oracle_trans_hit(C.addressof(flat.c), self._a(rp).ctypes.data, self._a(rd).ctypes.data,
-                                          nor.ctypes.data, C.byref(ex), C.byref(en))
+        a = self.lib.acn_oracle_trans_hit(C.addressof(flat.c), rp.ctypes.data, rd.ctypes.data, nor.ctypes.data,
+                                          C.byref(ex), C.byref(en))
         return a, nor, ex.value, en.value
 
     def random_seed(self, v, rv):
-        return self.lib.acn_oracle_random_seed(self._a(v).ctypes.data, rv)
+        v = self._a(v)
+        return self.lib.acn_oracle_random_seed(v.ctypes.data, rv)
 
     def sphere_cap(self, rv, h):
         s = C.c_uint64(rv)
