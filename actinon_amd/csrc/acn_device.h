@@ -587,7 +587,8 @@ DEVN double obj_ray_hit_dev( const DevScene& sc, int root, V3 rp, V3 rd, bool wa
             }
             if( sp == 0 )
             {
-                if( want_nor ) *out_nor = ret_n;
+                /* like the reference, the caller's normal is only written on a hit (obj_ray_exit relies on it) */
+                if( want_nor && ret_a < F3_INF ) *out_nor = ret_n;
                 return ret_a;
             }
             HitFrame& f = st[ sp - 1 ];
@@ -895,6 +896,7 @@ struct PathFrame
     uint64_t rv;
     uint64_t i, n;
     int depth;
+    int task_base;      /* the loop advances when the task stack is back at this height */
 };
 
 DEV void acc_add( V3* acc, V3 T, V3 c )
@@ -914,10 +916,10 @@ DEVN void lum_serial( const DevScene& sc, RayTask root, V3* acc, Counters* cnt )
 
     for( ;; )
     {
-        if( tsp == 0 )
+        /* Depth-first order as in the reference's recursion: a suspended path loop is advanced as soon as the rays
+         * it spawned are finished, and before any older sibling ray; so at most one loop per path level is live. */
+        if( fsp > 0 && tsp == frames[ fsp - 1 ].task_base )
         {
-            if( fsp == 0 ) return;
-            /* advance the innermost suspended path loop by one sample */
             PathFrame& f = frames[ fsp - 1 ];
             if( f.i >= f.n ) { fsp--; continue; }
             f.i++;
@@ -931,6 +933,7 @@ DEVN void lum_serial( const DevScene& sc, RayTask root, V3* acc, Counters* cnt )
             tasks[ tsp++ ] = t;
             continue;
         }
+        if( tsp == 0 ) return;
 
         RayTask t = tasks[ --tsp ];
         Trans trans;
@@ -1002,6 +1005,7 @@ DEVN void lum_serial( const DevScene& sc, RayTask root, V3* acc, Counters* cnt )
         }
 
         if( tsp + 3 > ACN_TASK_STACK ) { cnt->c[ CNT_OVERFLOW ]++; continue; }
+        bool new_frame = false;
 
         /* fresnel reflection :473-495 */
         if( fresnel_reflectivity > 0 && intensity >= min_intensity )
@@ -1061,7 +1065,8 @@ DEVN void lum_serial( const DevScene& sc, RayTask root, V3* acc, Counters* cnt )
                 if( fsp >= ACN_MAX_PATH_LEVELS ) { cnt->c[ CNT_OVERFLOW ]++; }
                 else
                 {
-                    PathFrame& f = frames[ fsp++ ];
+                    PathFrame& f = frames[ fsp ];
+                    new_frame = true;
                     f.s = s;
                     f.out_con = m_transposed( m_con_z( s.surface_d ) );
                     uint64_t path_samples = ( uint64_t )( sc.prm.path_samples * s.diffuse_intensity );
@@ -1082,6 +1087,9 @@ DEVN void lum_serial( const DevScene& sc, RayTask root, V3* acc, Counters* cnt )
             c.T = T; c.intensity = intensity; c.depth = depth - 1; c.kind = 0;
             tasks[ tsp++ ] = c;
         }
+
+        /* the path loop of this call runs before the sibling rays pushed above */
+        if( new_frame ) frames[ fsp++ ].task_base = tsp;
     }
 }
 

@@ -89,6 +89,22 @@ void k_render_serial( DevScene sc, const double* __restrict__ pos_xy, size_t fir
     if( counters ) wave_add_counters( counters, cnt );
 }
 
+/* cl_s_sat + cps_from_cl after the (cross-GPU) accumulation */
+__global__ void k_resolve( const double* __restrict__ lin, size_t n, double gamma, double* __restrict__ out_rgb,
+                           unsigned char* __restrict__ out_rgb8 )
+{
+    size_t i = ( size_t )blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n ) return;
+    V3 c = cl_sat( mk( lin[ i * 3 ], lin[ i * 3 + 1 ], lin[ i * 3 + 2 ] ), gamma );
+    if( out_rgb ) { out_rgb[ i * 3 ] = c.x; out_rgb[ i * 3 + 1 ] = c.y; out_rgb[ i * 3 + 2 ] = c.z; }
+    if( out_rgb8 )
+    {
+        out_rgb8[ i * 3 + 0 ] = c.x > 0.0 ? c.x < 1.0 ? ( unsigned char )( c.x * 256 ) : 255 : 0;
+        out_rgb8[ i * 3 + 1 ] = c.y > 0.0 ? c.y < 1.0 ? ( unsigned char )( c.y * 256 ) : 255 : 0;
+        out_rgb8[ i * 3 + 2 ] = c.z > 0.0 ? c.z < 1.0 ? ( unsigned char )( c.z * 256 ) : 255 : 0;
+    }
+}
+
 /* obj_ray_exit + obj_estimate_envelope (objects.c:286-363), one lane */
 __global__ void k_estimate_envelope( DevScene sc, int node, uint64_t samples, uint32_t rseed, double radius_factor,
                                      V3* scratch, double* out )
@@ -409,6 +425,20 @@ extern "C" int acn_render_positions( acn_scene_handle* h, const double* pos_xy, 
     if( st == ACN_OK && hipMemcpy( out_rgb, d_out, sizeof( double ) * 3 * n, hipMemcpyDeviceToHost ) != hipSuccess ) st = fail( ACN_ERR_DEVICE, "D2H copy failed" );
     hipFree( d_pos ); hipFree( d_out );
     return st;
+}
+
+extern "C" int acn_resolve_dev( acn_scene_handle* h, const void* d_linear_rgb, size_t n, void* d_out_rgb, void* d_out_rgb8,
+                                const acn_render_opts* opts )
+{
+    if( !h || ( n && !d_linear_rgb ) ) return fail( ACN_ERR_ARG, "null argument" );
+    if( n == 0 ) return ACN_OK;
+    HIP_TRY( hipSetDevice( h->device ) );
+    hipStream_t stream = ( opts && opts->stream ) ? ( hipStream_t )opts->stream : h->stream;
+    hipLaunchKernelGGL( k_resolve, dim3( ( unsigned )( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, stream,
+                        ( const double* )d_linear_rgb, n, h->dev.prm.gamma, ( double* )d_out_rgb, ( unsigned char* )d_out_rgb8 );
+    HIP_TRY( hipGetLastError() );
+    if( !( opts && opts->stream ) ) HIP_TRY( hipStreamSynchronize( stream ) );
+    return ACN_OK;
 }
 
 extern "C" int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms )

@@ -160,6 +160,11 @@ class Handle:
         o = self._opts(linear, stream)
         check(hip.acn_render_main_pass_dev(self.h, first, count, d_out_ptr, C.byref(o)), "acn_render_main_pass_dev")
 
+    def resolve_dev(self, d_linear_ptr, n, d_out_rgb_ptr=None, d_out_rgb8_ptr=None, stream=None):
+        """cl_s_sat + 8-bit pack on a device-resident linear radiance buffer (after accumulation / all-reduce)."""
+        o = self._opts(False, stream)
+        check(hip.acn_resolve_dev(self.h, d_linear_ptr, n, d_out_rgb_ptr, d_out_rgb8_ptr, C.byref(o)), "acn_resolve_dev")
+
     def last_kernel_ms(self):
         ms = C.c_double()
         check(hip.acn_last_kernel_ms(self.h, C.byref(ms)), "acn_last_kernel_ms")

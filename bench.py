@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s (pixels x path_samples) of the trace/radiance path on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one main pass (gradient_cycles = 0: one centre sample per pixel, /root/reference src/scene.c:1110-1119)
+over the whole frame: every rank renders linear radiance for its interleaved pixel tiles (actinon_amd/dist.py),
+the frame is completed by one RCCL sum all-reduce of the per-pixel accumulators (N > 1), rank 0 resolves
+(gamma + clamp + 8-bit pack, src/vectors.h:372-384, src/scene.c:76-82) and copies the 8-bit image to the host.
+The scene (flattened, device layout) and the per-rank pixel positions are resident in HBM before the timed region.
+
+Workload (config.workload): wine_glass.acn at 1920x1080, path_samples 64, direct_samples 200 -- the scene and
+sampling of BASELINE.json configs[1] at the resolution its metric is quoted on ("Msamples/s at 1920x1080").
+`--workload c2` runs configs[1] verbatim (1280x720).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM as BASELINE.json asks (the path
+is fp64-ALU bound, so frac is tiny by nature -- see DESIGN.md); `cpu_baseline` is the CPU oracle (a port of the
+reference's algorithm; the reference itself needs the absent library beth) timed on the host cores on a strided
+pixel subset of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene builder, overrides)
+    "wine_glass_1080p": ("wine_glass", dict(image_width=1920, image_height=1080, path_samples=64, direct_samples=200)),
+    "c2": ("wine_glass", dict(image_width=1280, image_height=720, path_samples=64, direct_samples=200)),
+    "c1": ("primitives", dict(image_width=400, image_height=300, path_samples=0, direct_samples=10)),
+    "c4": ("diamond", dict(image_width=1920, image_height=1080, path_samples=512, direct_samples=50)),
+    "c3": ("many_spheres:5:0", dict(image_width=1920, image_height=1080, path_samples=256, direct_samples=20)),
+    "smoke": ("wine_glass", dict(image_width=160, image_height=90, path_samples=16, direct_samples=50)),
+}
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def host_core_share():
+    """Host cores this job may use: the cgroup CPU quota if one is set (a 1-GPU box gets a share of the host),
+    else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get("ACN_BENCH_CPU_THREADS")
+    return int(env) if env else n
+
+
+def cpu_baseline(flat, width, height, path_samples, target_seconds=15.0):
+    """CPU oracle on a strided pixel subset of the same frame (same scene, same sampling), all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    from oracle_binding import Oracle
+    import actinon_amd as A
+    o = Oracle()
+    cores = host_core_share()
+    pos = A.main_pass_positions(width, height)
+    n = pos.shape[0]
+    # calibrate on ~1/400 of the frame, then size the sample for ~target_seconds
+    probe = pos[:: max(1, n // 4096)]
+    t0 = time.perf_counter()
+    o.render_positions(flat, probe, linear=True, threads=cores)
+    dt = max(time.perf_counter() - t0, 1e-3)
+    rate = probe.shape[0] / dt
+    want = int(min(n, max(probe.shape[0], rate * target_seconds)))
+    stride = max(1, n // want)
+    sample = pos[::stride]
+    t0 = time.perf_counter()
+    o.render_positions(flat, sample, linear=True, threads=cores)
+    dt = time.perf_counter() - t0
+    unit_scale = max(path_samples, 1)
+    return {
+        "value": sample.shape[0] * unit_scale / dt / 1e6,
+        "unit": "Msamples/s" if path_samples else "Mpixels/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"every {stride}th pixel of the {width}x{height} frame ({sample.shape[0]} pixels x {path_samples} "
+                  f"path samples, {dt:.1f} s, {cores} threads)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="wine_glass_1080p", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save-image", default=None, help="write the last frame as PNM (rank 0)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import actinon_amd as A
+    from actinon_amd import dist as adist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    builder, ov = WORKLOADS[args.workload]
+    scene = A.Scene.build(builder, **ov)
+    flat = scene.flatten()
+    W, H, S = int(flat.params.image_width), int(flat.params.image_height), int(flat.params.path_samples)
+    n_pix = W * H
+    handle = A.Handle(flat, device=local_rank)
+
+    # resident inputs: this rank's pixel positions; accumulators
+    idx_np = adist.rank_pixels(n_pix, rank, world)
+    pos = torch.from_numpy(adist.pixel_positions(idx_np, W)).to(dev)
+    idx = torch.from_numpy(idx_np).to(dev)
+    part = torch.empty((idx_np.shape[0], 3), dtype=torch.float64, device=dev)
+    frame = torch.zeros((n_pix, 3), dtype=torch.float64, device=dev)
+    rgb8 = torch.empty((n_pix, 3), dtype=torch.uint8, device=dev)
+    host_img = torch.empty((n_pix, 3), dtype=torch.uint8).pin_memory()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    kernel_ms = []
+
+    def step(record):
+        if world > 1:
+            handle.render_positions_dev(pos.data_ptr(), pos.shape[0], part.data_ptr(), linear=True, stream=stream)
+            frame.zero_()
+            frame.index_copy_(0, idx, part)
+            dist.all_reduce(frame, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                handle.resolve_dev(frame.data_ptr(), n_pix, None, rgb8.data_ptr(), stream=stream)
+                host_img.copy_(rgb8, non_blocking=True)
+        else:
+            handle.render_positions_dev(pos.data_ptr(), pos.shape[0], frame.data_ptr(), linear=True, stream=stream)
+            handle.resolve_dev(frame.data_ptr(), n_pix, None, rgb8.data_ptr(), stream=stream)
+            host_img.copy_(rgb8, non_blocking=True)
+        if record:
+            torch.cuda.synchronize()
+            kernel_ms.append(handle.last_kernel_ms())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel duration of the dominant kernel: HIP events recorded by the library on the launch stream
+    for _ in range(min(3, max(1, args.steps))):
+        step(True)
+    counters = handle.last_counters()
+    k_ms = float(np.mean(kernel_ms))
+
+    if rank == 0:
+        unit = max(S, 1)
+        value = n_pix * unit * args.steps / elapsed / 1e6
+        # algorithmic HBM bytes of one launch of the trace kernel on this rank (DESIGN.md "Roofline"):
+        # positions read (16 B) + radiance written (24 B) per pixel + one read of the flattened scene per workgroup
+        n_rank = idx_np.shape[0]
+        scene_bytes = flat.n_nodes * 304 + flat.c.n_elems * 4
+        workgroups = (n_rank + 63) // 64
+        alg_bytes = n_rank * (16 + 24) + workgroups * scene_bytes
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Msamples/s (pixels x path_samples), one main pass" if S else "Mpixels/s (path_samples = 0), one main pass",
+            "value": value,
+            "unit": "Msamples/s" if S else "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{builder} {W}x{H} path_samples={S} direct_samples={int(flat.params.direct_samples)} "
+                                   f"trace_depth={int(flat.params.trace_depth)} (BASELINE.json configs[1] scene+sampling"
+                                   f"{' at the metric resolution 1920x1080' if args.workload == 'wine_glass_1080p' else ''})"
+                       if builder == "wine_glass" else f"{builder} {W}x{H} path_samples={S} direct_samples={int(flat.params.direct_samples)}",
+                       "pixels": n_pix, "path_samples": S, "partition": f"pixel tiles of {adist.TILE}, round-robin over {world} rank(s)",
+                       "reduce": "RCCL all_reduce(sum, f64, W*H*3)" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_render", "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
+                         "note": "path is fp64-VALU bound; HBM roofline reported as BASELINE.json asks"},
+            "work": {"rays_per_step_rank0": counters["trans_rays"] + counters["shadow_rays"],
+                     "obj_hit_tests_rank0": counters["obj_hits"],
+                     "grays_per_s_rank0": (counters["trans_rays"] + counters["shadow_rays"]) / (k_ms * 1e-3) / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(flat, W, H, S)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+        if args.save_image:
+            from actinon_amd._lib import host
+            img = host_img.numpy().astype(np.float64) / 256.0 + 0.5 / 256.0
+            host.acn_write_pnm(args.save_image.encode(), img.ctypes.data, W, H)
+
+    handle.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

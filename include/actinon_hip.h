@@ -172,6 +172,12 @@ int acn_render_positions_dev( acn_scene_handle* h, const void* d_pos_xy, size_t 
 int acn_render_main_pass_dev( acn_scene_handle* h, size_t first, size_t count, void* d_out_rgb,
                               const acn_render_opts* opts );
 
+/* cl_s_sat (src/vectors.h:372-384) + cps_from_cl (src/scene.c:76-82) on a device-resident LINEAR radiance buffer,
+ * e.g. after the cross-GPU sum-reduce: d_out_rgb (nullable) receives the gamma-saturated colours [n][3] f64,
+ * d_out_rgb8 (nullable) the packed 8-bit pixels [n][3] u8 in PNM order. In-place (d_out_rgb == d_linear_rgb) allowed. */
+int acn_resolve_dev( acn_scene_handle* h, const void* d_linear_rgb, size_t n, void* d_out_rgb, void* d_out_rgb8,
+                     const acn_render_opts* opts );
+
 /* Timing of the kernels of the last render call on this handle (HIP events on the launch stream), ms. */
 int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms );
 
