@@ -22,7 +22,7 @@ host = _load("libactinon_host.so")
 
 # symbols declared by include/actinon_hip.h
 HIP_SYMBOLS = ["acn_device_count", "acn_scene_upload", "acn_scene_free", "acn_render_positions",
-               "acn_render_positions_dev", "acn_render_main_pass_dev", "acn_resolve_dev", "acn_last_kernel_ms", "acn_last_counters",
+               "acn_render_positions_dev", "acn_render_main_pass_dev", "acn_resolve_dev", "acn_last_kernel_ms", "acn_last_stage_ms", "acn_last_counters",
                "acn_estimate_envelope", "acn_detmath_eval", "acn_last_error"]
 # symbols declared by include/acn_scene.h
 HOST_SYMBOLS = ["acn_rotx", "acn_roty", "acn_rotz", "acn_obj_plane_s_create", "acn_obj_sphere_s_create",
@@ -55,6 +55,7 @@ hip.acn_render_positions_dev.argtypes = [vp, vp, C.c_size_t, vp, P(abi.RenderOpt
 hip.acn_render_main_pass_dev.argtypes = [vp, C.c_size_t, C.c_size_t, vp, P(abi.RenderOpts)]
 hip.acn_resolve_dev.argtypes = [vp, vp, C.c_size_t, vp, vp, P(abi.RenderOpts)]
 hip.acn_last_kernel_ms.argtypes = [vp, P(C.c_double)]
+hip.acn_last_stage_ms.argtypes = [vp, P(C.c_double), C.c_int]
 hip.acn_last_counters.argtypes = [vp, P(C.c_uint64), C.c_int]
 hip.acn_estimate_envelope.argtypes = [vp, C.c_int32, C.c_uint64, C.c_uint32, C.c_double, P(C.c_double)]
 hip.acn_detmath_eval.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_size_t]

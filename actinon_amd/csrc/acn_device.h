@@ -30,8 +30,12 @@
 #define F3_EPS 1E-6
 #define ACN_PI 3.14159265358979323846
 
+#ifndef ACN_CSG_MAX_DEPTH
 #define ACN_CSG_MAX_DEPTH   24   /* nesting of pair / neg / scale wrappers */
+#endif
+#ifndef ACN_CMP_MAX_DEPTH
 #define ACN_CMP_MAX_DEPTH   12   /* nesting of compounds */
+#endif
 #define ACN_TASK_STACK      64   /* pending rays per lane */
 #define ACN_MAX_PATH_LEVELS 5    /* suspended path loops: trace_depth <= 10 * 5 + 10 */
 
@@ -39,17 +43,57 @@ struct V3 { double x, y, z; };
 struct M3 { V3 x, y, z; };
 struct Ray { V3 p, d; };
 
+/* Device layout of a node: geometry only (192 B); shading properties live in GMat (96 B, read once per shading
+ * point).  Built from the ABI's acn_node by acn_scene_upload. */
+struct GNode
+{
+    int32_t  type;
+    uint32_t flags;
+    int32_t  child0, child1;
+    double   prm[ 4 ];
+    double   pos[ 3 ];
+    double   env_pos[ 3 ];
+    double   env_radius;
+    double   rax[ 9 ];
+    double   surface_roughness;
+    int32_t  sdf_kind, cycles;
+};
+
+struct GMat
+{
+    double color[ 3 ];
+    double radiance;
+    double refractive_index;
+    double fresnel_reflectivity;
+    double chromatic_reflectivity;
+    double diffuse_reflectivity;
+    double sigma;
+    double transparency[ 3 ];
+};
+
+/* The scene arrays are read through the CONSTANT address space: they never change while a kernel runs, so a load
+ * whose address is the same in every lane (root-compound loops, a wave's shading task) is issued as a scalar load
+ * (s_load -> SGPRs, scalar cache) and costs neither vector-memory bandwidth nor VGPRs; loads with per-lane
+ * addresses (inside CSG trees) become ordinary global loads. */
+#define ACN_CONST __attribute__( ( address_space( 4 ) ) )
+typedef const GNode   ACN_CONST* NodeP;
+typedef const GMat    ACN_CONST* MatP;
+typedef const int32_t ACN_CONST* ElemP;
+typedef const double  ACN_CONST* CDblP;
+
 /* device-resident scene */
 struct DevScene
 {
-    const acn_node* nodes;
-    const int32_t*  elems;
+    NodeP nodes;
+    MatP  mats;
+    ElemP elems;
     int32_t light_root, matter_root;
     uint32_t n_nodes, n_elems;
     acn_params prm;
     /* camera basis, computed on the device by k_camera_setup with the same expressions as the oracle */
     M3 camera_rotation;
     double unit_f;
+    uint32_t* flags;     /* device word for ACN_FLAG_* error bits */
 };
 
 enum
@@ -57,11 +101,36 @@ enum
     CNT_TRANS_RAY = 0, CNT_SHADOW_RAY, CNT_OBJ_HIT, CNT_LUM, CNT_CAP_SAMPLE, CNT_SIDE, CNT_SDF_EVAL, CNT_OVERFLOW, CNT_N
 };
 
-struct Counters { unsigned long long c[ CNT_N ]; };
+/* per-lane event counts of one launch (32 bit each), wave-reduced into 64-bit global counters at kernel end.
+ * Cnt< false > compiles to nothing: the counting kernels are only used when ACN_OPT_COUNT_WORK is set. */
+template< bool ON > struct Cnt;
+template<> struct Cnt< true >
+{
+    unsigned c[ CNT_N ];
+    __device__ __forceinline__ void clear() { for( int k = 0; k < CNT_N; k++ ) c[ k ] = 0; }
+    __device__ __forceinline__ void inc( int k ) { c[ k ]++; }
+    __device__ __forceinline__ void add( int k, unsigned v ) { c[ k ] += v; }
+};
+template<> struct Cnt< false >
+{
+    __device__ __forceinline__ void clear() {}
+    __device__ __forceinline__ void inc( int ) {}
+    __device__ __forceinline__ void add( int, unsigned ) {}
+};
+
+/* the two read-only scene arrays, passed BY VALUE into the non-inlined machines (global address space, so the
+ * scene struct is never forced into scratch) */
+struct SceneRef { NodeP nodes; ElemP elems; uint32_t* flags; };
+#define ACN_FLAG_TASK_OVERFLOW  1u
+#define ACN_FLAG_CHILD_OVERFLOW 2u
+#define ACN_FLAG_STACK_OVERFLOW 4u   /* CSG / compound / ray stack exhausted: the result would be wrong, the call fails */
+__device__ __forceinline__ SceneRef sref( const DevScene& sc ) { SceneRef r; r.nodes = sc.nodes; r.elems = sc.elems; r.flags = sc.flags; return r; }
 
 /* ---- vectors.h ---- */
 DEV V3 mk( double x, double y, double z ) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
 DEV V3 ld3( const double* p ) { return mk( p[ 0 ], p[ 1 ], p[ 2 ] ); }
+DEV V3 ld3( CDblP p ) { return mk( p[ 0 ], p[ 1 ], p[ 2 ] ); }
+DEV V3 ldc( const V3 ACN_CONST& v ) { return mk( v.x, v.y, v.z ); }
 DEV V3 v_neg( V3 o ) { return mk( -o.x, -o.y, -o.z ); }
 DEV double v_sqr( V3 o ) { return ( o.x * o.x ) + ( o.y * o.y ) + ( o.z * o.z ); }
 DEV V3 v_add( V3 o, V3 s ) { return mk( o.x + s.x, o.y + s.y, o.z + s.z ); }
@@ -280,21 +349,21 @@ DEV V3 fresnel_refraction( V3 dir_i, V3 exit_nor, double trix )
 }
 
 /* ---- node access ---- */
-DEV bool node_has_env( const acn_node* n ) { return ( n->flags & ACN_NODE_HAS_ENVELOPE ) != 0; }
-DEV M3 node_rax( const acn_node* n )
+DEV bool node_has_env( NodeP n ) { return ( n->flags & ACN_NODE_HAS_ENVELOPE ) != 0; }
+DEV M3 node_rax( NodeP n )
 {
     M3 m;
     m.x = ld3( n->rax ); m.y = ld3( n->rax + 3 ); m.z = ld3( n->rax + 6 );
     return m;
 }
-DEV bool env_ray_hits( const acn_node* n, V3 rp, V3 rd )   /* objects.c:90-93 */
+DEV bool env_ray_hits( NodeP n, V3 rp, V3 rd )   /* objects.c:90-93 */
 {
     return sphere_ray_hit( ld3( n->env_pos ), n->env_radius, rp, rd, false, nullptr ) < F3_INF;
 }
-DEV int env_side( const acn_node* n, V3 pos ) { return sphere_observer_side( ld3( n->env_pos ), n->env_radius, pos ); }
+DEV int env_side( NodeP n, V3 pos ) { return sphere_observer_side( ld3( n->env_pos ), n->env_radius, pos ); }
 
 /* ---- distance.c:39-42, 83-92 ---- */
-DEV double sdf_eval( const acn_node* n, V3 pos )
+DEV double sdf_eval( NodeP n, V3 pos )
 {
     if( n->sdf_kind == ACN_SDF_TORUS )
     {
@@ -310,7 +379,7 @@ DEV double sdf_eval( const acn_node* n, V3 pos )
 }
 
 /* ---- leaves ---- */
-DEV double squaroid_ray_hit( const acn_node* o, V3 rp, V3 rd, bool want_nor, V3* p_nor )   /* objects.c:778-821 */
+DEV double squaroid_ray_hit( NodeP o, V3 rp, V3 rd, bool want_nor, V3* p_nor )   /* objects.c:778-821 */
 {
     M3 rax = node_rax( o );
     double oa = o->prm[ 0 ], ob = o->prm[ 1 ], oc = o->prm[ 2 ], orr = o->prm[ 3 ];
@@ -348,14 +417,15 @@ DEV double squaroid_ray_hit( const acn_node* o, V3 rp, V3 rd, bool want_nor, V3*
     return a - F3_EPS;
 }
 
-DEV int squaroid_side( const acn_node* o, V3 pos )   /* objects.c:823-827 */
+DEV int squaroid_side( NodeP o, V3 pos )   /* objects.c:823-827 */
 {
     M3 rax = node_rax( o );
     V3 p = m_mlv( rax, v_sub( pos, ld3( o->pos ) ) );
     return ( o->prm[ 0 ] * p.x * p.x + o->prm[ 1 ] * p.y * p.y + o->prm[ 2 ] * p.z * p.z + o->prm[ 3 ] ) > 0 ? 1 : -1;
 }
 
-DEVN double distance_ray_hit( const acn_node* o, V3 rp, V3 rd, bool want_nor, V3* p_nor, Counters* cnt )   /* objects.c:903-959 */
+template< class CT >
+DEVN double distance_ray_hit( NodeP o, V3 rp, V3 rd, bool want_nor, V3* p_nor, CT* cnt )   /* objects.c:903-959 */
 {
     M3 rax = node_rax( o );
     double inv_scale = o->prm[ 0 ];
@@ -397,7 +467,7 @@ DEVN double distance_ray_hit( const acn_node* o, V3 rp, V3 rd, bool want_nor, V3
             if( dist > 0 || dist < -F3_MAG ) break;
         }
     }
-    cnt->c[ CNT_SDF_EVAL ] += evals;
+    cnt->add( CNT_SDF_EVAL, evals );
     if( f_abs( dist ) <= F3_EPS )
     {
         if( want_nor )
@@ -415,7 +485,7 @@ DEVN double distance_ray_hit( const acn_node* o, V3 rp, V3 rd, bool want_nor, V3
     return F3_INF;
 }
 
-DEV int distance_side( const acn_node* o, V3 pos )   /* objects.c:961-966 */
+DEV int distance_side( NodeP o, V3 pos )   /* objects.c:961-966 */
 {
     if( node_has_env( o ) && env_side( o, pos ) == 1 ) return 1;
     M3 rax = node_rax( o );
@@ -427,7 +497,8 @@ DEV int distance_side( const acn_node* o, V3 pos )   /* objects.c:961-966 */
 /* side machine: obj_side (objects.c:365-370) over the CSG tree, iteratively. */
 struct SideFrame { int node; int pc; V3 pos; };
 
-DEVN int obj_side_dev( const DevScene& sc, int root, V3 pos, Counters* cnt )
+template< class CT >
+DEVN int obj_side_dev( SceneRef sc, int root, V3 pos, CT* cnt )
 {
     SideFrame st[ ACN_CSG_MAX_DEPTH ];
     int sp = 0;
@@ -436,8 +507,8 @@ DEVN int obj_side_dev( const DevScene& sc, int root, V3 pos, Counters* cnt )
     for( ;; )
     {
         /* ENTER( node, pos ) */
-        const acn_node* n = &sc.nodes[ node ];
-        cnt->c[ CNT_SIDE ]++;
+        NodeP n = &sc.nodes[ node ];
+        cnt->inc( CNT_SIDE );
         bool returned = true;
         if( node_has_env( n ) && env_side( n, pos ) == 1 )
         {
@@ -450,16 +521,16 @@ DEVN int obj_side_dev( const DevScene& sc, int root, V3 pos, Counters* cnt )
                 case ACN_PLANE:    r = v_sub_mlv( pos, ld3( n->pos ), ld3( n->rax + 6 ) ) > 0 ? 1 : -1; break;   /* gmath.h:52-55 */
                 case ACN_SPHERE:   r = sphere_observer_side( ld3( n->pos ), n->prm[ 0 ], pos ); break;
                 case ACN_SQUAROID: r = squaroid_side( n, pos ); break;
-                case ACN_DISTANCE: r = distance_side( n, pos ); cnt->c[ CNT_SDF_EVAL ]++; break;
+                case ACN_DISTANCE: r = distance_side( n, pos ); cnt->inc( CNT_SDF_EVAL ); break;
                 case ACN_PAIR_INSIDE: case ACN_PAIR_OUTSIDE: case ACN_NEG:
-                    if( sp >= ACN_CSG_MAX_DEPTH ) { cnt->c[ CNT_OVERFLOW ]++; r = 1; break; }
+                    if( sp >= ACN_CSG_MAX_DEPTH ) { atomicOr( sc.flags, ACN_FLAG_STACK_OVERFLOW ); r = 1; break; }
                     st[ sp ].node = node; st[ sp ].pc = 1; st[ sp ].pos = pos; sp++;
                     node = n->child0;
                     returned = false;
                     break;
                 case ACN_SCALE:   /* objects.c:1439-1443 */
                 {
-                    if( sp >= ACN_CSG_MAX_DEPTH ) { cnt->c[ CNT_OVERFLOW ]++; r = 1; break; }
+                    if( sp >= ACN_CSG_MAX_DEPTH ) { atomicOr( sc.flags, ACN_FLAG_STACK_OVERFLOW ); r = 1; break; }
                     st[ sp ].node = node; st[ sp ].pc = 1; st[ sp ].pos = pos; sp++;
                     M3 rax = node_rax( n );
                     V3 p = m_mlv( rax, v_sub( pos, ld3( n->pos ) ) );
@@ -476,7 +547,7 @@ DEVN int obj_side_dev( const DevScene& sc, int root, V3 pos, Counters* cnt )
         {
             if( sp == 0 ) return r;
             SideFrame& f = st[ sp - 1 ];
-            const acn_node* fn = &sc.nodes[ f.node ];
+            NodeP fn = &sc.nodes[ f.node ];
             if( fn->type == ACN_NEG ) { r = -r; sp--; }                                   /* objects.c:1341-1344 */
             else if( fn->type == ACN_SCALE ) { sp--; }
             else
@@ -501,15 +572,14 @@ DEVN int obj_side_dev( const DevScene& sc, int root, V3 pos, Counters* cnt )
 /* hit machine: obj_ray_hit (objects.c:261-284) with pair / neg / scale recursion unrolled into frames. */
 struct HitFrame
 {
-    int node; int pc; int swapped; int pad;
+    int node; short pc; short swapped;
     double a1;        /* pair: a1 | scale: d_factor */
-    double offs;      /* pair: a2, later the walk offset */
+    double offs;      /* pair: the walk offset */
     V3 n1;            /* pair: n1 | scale: saved ray direction */
-    V3 n2;
     V3 rp;            /* origin of the ray this call received */
 };
 
-DEV V3 roughness_normal( const acn_node* hdr, V3 n, V3 hit_pos )   /* objects.c:267-282 */
+DEV V3 roughness_normal( NodeP hdr, V3 n, V3 hit_pos )   /* objects.c:267-282 */
 {
     uint64_t rv = v_random_seed( hit_pos, 1246 );
     double f;
@@ -522,7 +592,8 @@ DEV V3 roughness_normal( const acn_node* hdr, V3 n, V3 hit_pos )   /* objects.c:
     return v_of_length( n, 1.0 );
 }
 
-DEVN double obj_ray_hit_dev( const DevScene& sc, int root, V3 rp, V3 rd, bool want_nor, V3* out_nor, Counters* cnt )
+template< class CT >
+DEVN double obj_ray_hit_dev( SceneRef sc, int root, V3 rp, V3 rd, bool want_nor, V3* out_nor, CT* cnt )
 {
     /* fast path: a leaf needs no frame */
     HitFrame st[ ACN_CSG_MAX_DEPTH ];
@@ -533,8 +604,8 @@ DEVN double obj_ray_hit_dev( const DevScene& sc, int root, V3 rp, V3 rd, bool wa
     for( ;; )
     {
         /* ---- ENTER( node, rp, rd ) ---- */
-        const acn_node* n = &sc.nodes[ node ];
-        cnt->c[ CNT_OBJ_HIT ]++;
+        NodeP n = &sc.nodes[ node ];
+        cnt->inc( CNT_OBJ_HIT );
         bool returned = true;   /* false: a child call was issued */
         if( node_has_env( n ) && !env_ray_hits( n, rp, rd ) )
         {
@@ -549,14 +620,14 @@ DEVN double obj_ray_hit_dev( const DevScene& sc, int root, V3 rp, V3 rd, bool wa
                 case ACN_SQUAROID: ret_a = squaroid_ray_hit( n, rp, rd, want_nor, &ret_n ); break;
                 case ACN_DISTANCE: ret_a = distance_ray_hit( n, rp, rd, want_nor, &ret_n, cnt ); break;
                 case ACN_PAIR_INSIDE: case ACN_PAIR_OUTSIDE: case ACN_NEG:
-                    if( sp >= ACN_CSG_MAX_DEPTH ) { cnt->c[ CNT_OVERFLOW ]++; ret_a = F3_INF; break; }
+                    if( sp >= ACN_CSG_MAX_DEPTH ) { atomicOr( sc.flags, ACN_FLAG_STACK_OVERFLOW ); ret_a = F3_INF; break; }
                     st[ sp ].node = node; st[ sp ].pc = 1; st[ sp ].swapped = 0; st[ sp ].rp = rp; sp++;
                     node = n->child0;
                     returned = false;
                     break;
                 case ACN_SCALE:   /* objects.c:1418-1428 */
                 {
-                    if( sp >= ACN_CSG_MAX_DEPTH ) { cnt->c[ CNT_OVERFLOW ]++; ret_a = F3_INF; break; }
+                    if( sp >= ACN_CSG_MAX_DEPTH ) { atomicOr( sc.flags, ACN_FLAG_STACK_OVERFLOW ); ret_a = F3_INF; break; }
                     M3 rax = node_rax( n );
                     V3 inv_scale = mk( n->prm[ 0 ], n->prm[ 1 ], n->prm[ 2 ] );
                     V3 p2 = v_mld( m_mlv( rax, v_sub( rp, ld3( n->pos ) ) ), inv_scale );
@@ -579,7 +650,7 @@ DEVN double obj_ray_hit_dev( const DevScene& sc, int root, V3 rp, V3 rd, bool wa
         {
             /* POST of `node` called with ( rp, rd ): roughness, objects.c:266-282 */
             {
-                const acn_node* hdr = &sc.nodes[ node ];
+                NodeP hdr = &sc.nodes[ node ];
                 if( want_nor && ret_a < F3_INF && hdr->surface_roughness > 0 )
                 {
                     ret_n = roughness_normal( hdr, ret_n, ray_pos( rp, rd, ret_a ) );
@@ -592,7 +663,7 @@ DEVN double obj_ray_hit_dev( const DevScene& sc, int root, V3 rp, V3 rd, bool wa
                 return ret_a;
             }
             HitFrame& f = st[ sp - 1 ];
-            const acn_node* fn = &sc.nodes[ f.node ];
+            NodeP fn = &sc.nodes[ f.node ];
             if( fn->type == ACN_NEG )   /* objects.c:1329-1339 */
             {
                 if( ret_a < F3_INF ) ret_n = v_neg( ret_n );
@@ -694,16 +765,18 @@ DEVN double obj_ray_hit_dev( const DevScene& sc, int root, V3 rp, V3 rd, bool wa
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* compounds: compound.c:215-299 */
 
-/* closest hit inside compound `cmp` (recursing into nested compounds). limit: stop as soon as a hit <= limit is
- * found (any-hit for occlusion: "compound_s_ray_hit( matter ) > a" is false iff some element hits at <= a). */
-DEVN double compound_ray_hit_dev( const DevScene& sc, int cmp, V3 rp, V3 rd, bool want_nor, V3* p_nor, int* hit_obj,
-                                  double limit, Counters* cnt )
+/* Generic (per-lane indices) closest hit inside compound `cmp`, recursing into nested compounds with an explicit
+ * stack. limit: stop as soon as a hit <= limit is found (any-hit for occlusion: "compound_s_ray_hit( matter ) > a"
+ * is false iff some element hits at <= a). */
+template< class CT >
+DEVN double compound_ray_hit_dev( SceneRef sc, int cmp, V3 rp, V3 rd, bool want_nor, V3* p_nor, int* hit_obj,
+                                  double limit, CT* cnt )
 {
     int st_i[ ACN_CMP_MAX_DEPTH ], st_end[ ACN_CMP_MAX_DEPTH ];
     int sp = 0;
     double min_a = F3_INF;
     {
-        const acn_node* o = &sc.nodes[ cmp ];
+        NodeP o = &sc.nodes[ cmp ];
         if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) return F3_INF;
         st_i[ 0 ] = o->child0; st_end[ 0 ] = o->child0 + o->child1; sp = 1;
     }
@@ -711,11 +784,11 @@ DEVN double compound_ray_hit_dev( const DevScene& sc, int cmp, V3 rp, V3 rd, boo
     {
         if( st_i[ sp - 1 ] >= st_end[ sp - 1 ] ) { sp--; continue; }
         int element = sc.elems[ st_i[ sp - 1 ]++ ];
-        const acn_node* e = &sc.nodes[ element ];
+        NodeP e = &sc.nodes[ element ];
         if( e->type == ACN_COMPOUND )
         {
             if( node_has_env( e ) && !env_ray_hits( e, rp, rd ) ) continue;
-            if( sp >= ACN_CMP_MAX_DEPTH ) { cnt->c[ CNT_OVERFLOW ]++; continue; }
+            if( sp >= ACN_CMP_MAX_DEPTH ) { atomicOr( sc.flags, ACN_FLAG_STACK_OVERFLOW ); continue; }
             st_i[ sp ] = e->child0; st_end[ sp ] = e->child0 + e->child1; sp++;
             continue;
         }
@@ -732,30 +805,63 @@ DEVN double compound_ray_hit_dev( const DevScene& sc, int cmp, V3 rp, V3 rd, boo
     return min_a;
 }
 
+/* Hit test of ROOT element `e` (an index that is the same in every active lane of the wave, so the node is read
+ * through the scalar cache into SGPRs and the type dispatch is a scalar branch): obj_ray_hit (objects.c:261-284)
+ * for objects -- plane / sphere / squaroid inline, CSG and SDF objects through the hit machine -- and
+ * compound_s_ray_hit for nested compounds. */
+template< bool NOR, class CT >
+DEV double element_hit( const DevScene& sc, int e, V3 rp, V3 rd, V3* nor, int* hit_obj, double limit, CT* cnt )
+{
+    NodeP n = &sc.nodes[ e ];
+    int type = n->type;
+    if( type == ACN_COMPOUND ) return compound_ray_hit_dev( sref( sc ), e, rp, rd, NOR, nor, hit_obj, limit, cnt );
+    *hit_obj = e;
+    bool env = node_has_env( n );
+    if( env && !env_ray_hits( n, rp, rd ) ) { cnt->inc( CNT_OBJ_HIT ); return F3_INF; }
+    if( type > ACN_SQUAROID ) return obj_ray_hit_dev( sref( sc ), e, rp, rd, NOR, nor, cnt );   /* the machine redoes the envelope test */
+    cnt->inc( CNT_OBJ_HIT );
+    double a;
+    if( type == ACN_PLANE )       a = plane_ray_hit( ld3( n->pos ), ld3( n->rax + 6 ), rp, rd, NOR, nor );
+    else if( type == ACN_SPHERE ) a = sphere_ray_hit( ld3( n->pos ), n->prm[ 0 ], rp, rd, NOR, nor );
+    else                          a = squaroid_ray_hit( n, rp, rd, NOR, nor );
+    if( NOR && a < F3_INF && n->surface_roughness > 0 ) *nor = roughness_normal( n, *nor, ray_pos( rp, rd, a ) );
+    return a;
+}
+
+/* compound_s_ray_hit on a root compound, any-hit form for occlusion tests: true iff some element hits at <= limit */
+template< class CT >
+DEV bool root_occluded( const DevScene& sc, int cmp, V3 rp, V3 rd, double limit, CT* cnt )
+{
+    NodeP o = &sc.nodes[ cmp ];
+    if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) return false;
+    int first = o->child0, count = o->child1;
+    for( int i = 0; i < count; i++ )
+    {
+        int element = __builtin_amdgcn_readfirstlane( sc.elems[ first + i ] );
+        int hit_obj;
+        double a = element_hit< false >( sc, element, rp, rd, nullptr, &hit_obj, limit, cnt );
+        if( a <= limit ) return true;
+    }
+    return false;
+}
+
 struct Trans { V3 exit_nor; int exit_obj; int enter_obj; };
 
-DEVN double compound_ray_trans_hit_dev( const DevScene& sc, int cmp, V3 rp, V3 rd, Trans* trans, Counters* cnt )
+/* compound_s_ray_trans_hit on a root compound (compound.c:246-299) */
+template< class CT >
+DEV double root_trans_hit( const DevScene& sc, int cmp, V3 rp, V3 rd, Trans* trans, CT* cnt )
 {
-    const acn_node* o = &sc.nodes[ cmp ];
-    cnt->c[ CNT_TRANS_RAY ]++;
+    NodeP o = &sc.nodes[ cmp ];
+    cnt->inc( CNT_TRANS_RAY );
     if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) return F3_INF;
     double min_a = F3_INF;
     int first = o->child0, count = o->child1;
     for( int i = 0; i < count; i++ )
     {
-        int element = sc.elems[ first + i ];
+        int element = __builtin_amdgcn_readfirstlane( sc.elems[ first + i ] );
         int hit_obj = -1;
         V3 nor = mk( 0, 0, 0 );
-        double a;
-        if( sc.nodes[ element ].type == ACN_COMPOUND )
-        {
-            a = compound_ray_hit_dev( sc, element, rp, rd, true, &nor, &hit_obj, -F3_INF, cnt );
-        }
-        else
-        {
-            hit_obj = element;
-            a = obj_ray_hit_dev( sc, element, rp, rd, true, &nor, cnt );
-        }
+        double a = element_hit< true >( sc, element, rp, rd, &nor, &hit_obj, -F3_INF, cnt );
         if( a < F3_INF )
         {
             if( a < min_a - F3_EPS )
@@ -781,18 +887,19 @@ DEVN double compound_ray_trans_hit_dev( const DevScene& sc, int cmp, V3 rp, V3 r
     return min_a;
 }
 
-DEV double scene_trans_hit_dev( const DevScene& sc, V3 rp, V3 rd, Trans* trans, Counters* cnt )   /* scene.c:362-382 */
+template< class CT >
+DEV double scene_trans_hit_dev( const DevScene& sc, V3 rp, V3 rd, Trans* trans, CT* cnt )   /* scene.c:362-382 */
 {
     double min_a = F3_INF;
     double a;
     Trans trans_l;
     trans_l.exit_nor = mk( 0, 0, 0 ); trans_l.exit_obj = -1; trans_l.enter_obj = -1;
-    if( ( a = compound_ray_trans_hit_dev( sc, sc.light_root, rp, rd, &trans_l, cnt ) ) < min_a )
+    if( ( a = root_trans_hit( sc, sc.light_root, rp, rd, &trans_l, cnt ) ) < min_a )
     {
         min_a = a;
         *trans = trans_l;
     }
-    if( ( a = compound_ray_trans_hit_dev( sc, sc.matter_root, rp, rd, &trans_l, cnt ) ) < min_a )
+    if( ( a = root_trans_hit( sc, sc.matter_root, rp, rd, &trans_l, cnt ) ) < min_a )
     {
         min_a = a;
         *trans = trans_l;
@@ -810,7 +917,7 @@ DEV void sphere_fov( V3 center, double radius, V3 pos, V3* dir, double* cos_rs )
     *cos_rs = ( diff_sqr > radius_sqr ) ? acn_sqrt( 1.0 - ( radius_sqr / diff_sqr ) ) : -1;
 }
 
-DEV void obj_fov_dev( const acn_node* o, V3 pos, V3* dir, double* cos_rs )
+DEV void obj_fov_dev( NodeP o, V3 pos, V3* dir, double* cos_rs )
 {
     if( o->type == ACN_PLANE )
     {
@@ -842,255 +949,6 @@ DEV double oren_nayar_weight( double weight, double theta_i, double on_a, double
     acn_sincos( ta, &s1, &c1 );
     acn_sincos( tb, &s2, &c2 );
     return weight * ( on_a + ( on_b * f_max( cos_phi, 0 ) * s1 * ( s2 / c2 ) ) );
-}
-
-/* ------------------------------------------------------------------------------------------------------------------ */
-/* the shading context of one diffuse shading point (scene.c:526-537) */
-struct ShadeCtx
-{
-    V3 pos;              /* surface.p */
-    V3 surface_d;        /* -exit_nor */
-    V3 ray_projection;
-    double theta_i, on_a, on_b;
-    double diffuse_intensity;
-};
-
-/* one direct-light sample j of light `light_idx` (scene.c:556-576); returns its contribution to cl_sum / color */
-DEV double direct_sample( const DevScene& sc, const ShadeCtx& s, int light_idx, const acn_node* light_src, const M3& src_con,
-                          double cyl_hgt, uint64_t* rv, Counters* cnt )
-{
-    cnt->c[ CNT_CAP_SAMPLE ]++;
-    V3 out_d = m_mlv( src_con, v_random_sphere_cap( rv, cyl_hgt ) );
-    double weight = v_mlv( out_d, s.surface_d );
-    if( weight <= 0 ) return 0;
-    double a = obj_ray_hit_dev( sc, light_idx, s.pos, out_d, false, nullptr, cnt );
-    if( a >= F3_INF ) return 0;
-    if( s.on_b > 0 ) weight = oren_nayar_weight( weight, s.theta_i, s.on_a, s.on_b, out_d, s.surface_d, s.ray_projection );
-    cnt->c[ CNT_SHADOW_RAY ]++;
-    if( compound_ray_hit_dev( sc, sc.matter_root, s.pos, out_d, false, nullptr, nullptr, a, cnt ) > a )
-    {
-        V3 hit_pos = ray_pos( s.pos, out_d, a );
-        double diff_sqr = v_diff_sqr( hit_pos, ld3( light_src->pos ) );
-        double local_intensity = ( diff_sqr > 0 ) ? ( light_src->radiance / diff_sqr ) : F3_MAG;
-        return local_intensity * weight * s.diffuse_intensity;
-    }
-    return 0;
-}
-
-/* pending ray of the lum evaluator */
-struct RayTask
-{
-    V3 p, d;
-    V3 T;               /* colour throughput applied to whatever this ray returns */
-    double intensity;
-    int depth;
-    int kind;           /* 0: scene_s_trans_hit ray (reflection/refraction/primary); 1: path ray (matter only) */
-};
-
-/* suspended path loop (scene.c:584-621) */
-struct PathFrame
-{
-    ShadeCtx s;
-    M3 out_con;
-    V3 T;               /* T_parent * enter_color * ( 2.0 / path_samples ) */
-    uint64_t rv;
-    uint64_t i, n;
-    int depth;
-    int task_base;      /* the loop advances when the task stack is back at this height */
-};
-
-DEV void acc_add( V3* acc, V3 T, V3 c )
-{
-    acc->x += T.x * c.x; acc->y += T.y * c.y; acc->z += T.z * c.z;
-}
-
-/* Serial (one lane) evaluation of scene_s_lum for the ray tree rooted at `root`. Adds into *acc. */
-DEVN void lum_serial( const DevScene& sc, RayTask root, V3* acc, Counters* cnt )
-{
-    RayTask tasks[ ACN_TASK_STACK ];
-    PathFrame frames[ ACN_MAX_PATH_LEVELS ];
-    int tsp = 0, fsp = 0;
-    tasks[ tsp++ ] = root;
-    const double min_intensity = sc.prm.trace_min_intensity;
-    const V3 bg = ld3( sc.prm.background_color );
-
-    for( ;; )
-    {
-        /* Depth-first order as in the reference's recursion: a suspended path loop is advanced as soon as the rays
-         * it spawned are finished, and before any older sibling ray; so at most one loop per path level is live. */
-        if( fsp > 0 && tsp == frames[ fsp - 1 ].task_base )
-        {
-            PathFrame& f = frames[ fsp - 1 ];
-            if( f.i >= f.n ) { fsp--; continue; }
-            f.i++;
-            cnt->c[ CNT_CAP_SAMPLE ]++;
-            V3 out_d = m_mlv( f.out_con, v_random_sphere_cap( &f.rv, 1.0 ) );
-            double weight = v_mlv( out_d, f.s.surface_d );
-            if( weight <= 0 ) continue;
-            if( f.s.on_b > 0 ) weight = oren_nayar_weight( weight, f.s.theta_i, f.s.on_a, f.s.on_b, out_d, f.s.surface_d, f.s.ray_projection );
-            RayTask t;
-            t.p = f.s.pos; t.d = out_d; t.T = f.T; t.intensity = weight * f.s.diffuse_intensity; t.depth = f.depth - 10; t.kind = 1;
-            tasks[ tsp++ ] = t;
-            continue;
-        }
-        if( tsp == 0 ) return;
-
-        RayTask t = tasks[ --tsp ];
-        Trans trans;
-        trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
-        double offs;
-        if( t.kind == 0 )
-        {
-            offs = scene_trans_hit_dev( sc, t.p, t.d, &trans, cnt );
-            if( !( offs < F3_INF ) ) { acc_add( acc, t.T, v_mlf( bg, t.intensity ) ); continue; }
-        }
-        else
-        {
-            offs = compound_ray_trans_hit_dev( sc, sc.matter_root, t.p, t.d, &trans, cnt );
-            if( !( offs < sc.prm.max_path_length ) ) { acc_add( acc, t.T, v_mlf( bg, t.intensity ) ); continue; }
-        }
-
-        /* ---- scene_s_lum( ray = t, offs, trans, depth, intensity ) scene.c:420-667 ---- */
-        int depth = t.depth;
-        double intensity = t.intensity;
-        if( depth == 0 || intensity < min_intensity ) continue;
-        cnt->c[ CNT_LUM ]++;
-        V3 pos = ray_pos( t.p, t.d, offs );
-        const acn_node* enter_obj = trans.enter_obj >= 0 ? &sc.nodes[ trans.enter_obj ] : nullptr;
-        const acn_node* exit_obj  = trans.exit_obj  >= 0 ? &sc.nodes[ trans.exit_obj  ] : nullptr;
-
-        if( enter_obj && enter_obj->radiance > 0 )
-        {
-            double diff_sqr = v_diff_sqr( pos, ld3( enter_obj->pos ) );
-            double light_intensity = ( diff_sqr > 0 ) ? ( enter_obj->radiance / diff_sqr ) : F3_MAG;
-            acc_add( acc, t.T, v_mlf( ld3( enter_obj->color ), light_intensity * intensity ) );
-            continue;
-        }
-
-        double trix = 1.0;
-        double fresnel_reflectivity = 0, chromatic_reflectivity = 0, diffuse_reflectivity = 0;
-        double on_a = 1.0, on_b = 0.0;
-        bool transparent = false;
-        V3 enter_color = mk( 1, 1, 1 );
-        if( enter_obj )
-        {
-            trix = enter_obj->refractive_index;
-            fresnel_reflectivity   = ( enter_obj->fresnel_reflectivity != 0 && enter_obj->refractive_index != 1.0 ) ? 1.0 : 0.0;
-            chromatic_reflectivity = enter_obj->chromatic_reflectivity;
-            diffuse_reflectivity   = enter_obj->diffuse_reflectivity;
-            transparent            = v_sqr( ld3( enter_obj->transparency ) ) > 0;
-            double sigma           = enter_obj->sigma;
-            if( sigma > 0 )
-            {
-                double sigma_sqr = f_sqr( sigma );
-                on_a = 1.0 - 0.5 * sigma_sqr / ( sigma_sqr + 0.33 );
-                on_b = 0.45 * sigma_sqr / ( sigma_sqr + 0.09 );
-            }
-            enter_color = ld3( enter_obj->color );
-        }
-        V3 T = t.T;
-        if( exit_obj )
-        {
-            trix /= exit_obj->refractive_index;
-            fresnel_reflectivity = 1.0;
-            diffuse_reflectivity = chromatic_reflectivity = 0;
-            transparent = true;
-            /* exiting object scene.c:656-664: the absorption factor multiplies everything this call returns */
-            if( offs > 0 )
-            {
-                T.x *= acn_pow( exit_obj->transparency[ 0 ], offs );
-                T.y *= acn_pow( exit_obj->transparency[ 1 ], offs );
-                T.z *= acn_pow( exit_obj->transparency[ 2 ], offs );
-            }
-        }
-
-        if( tsp + 3 > ACN_TASK_STACK ) { cnt->c[ CNT_OVERFLOW ]++; continue; }
-        bool new_frame = false;
-
-        /* fresnel reflection :473-495 */
-        if( fresnel_reflectivity > 0 && intensity >= min_intensity )
-        {
-            V3 out_d;
-            double reflectance = fresnel_reflection( t.d, trans.exit_nor, trix, &out_d ) * fresnel_reflectivity;
-            RayTask c;
-            c.p = pos; c.d = out_d; c.T = T; c.intensity = reflectance * intensity; c.depth = depth - 1; c.kind = 0;
-            tasks[ tsp++ ] = c;
-            intensity *= ( 1.0 - reflectance );
-        }
-
-        /* chromatic reflection :498-523 */
-        if( chromatic_reflectivity > 0 && intensity >= min_intensity )
-        {
-            RayTask c;
-            c.p = pos; c.d = v_reflection( t.d, trans.exit_nor ); c.T = v_mld( T, enter_color );
-            c.intensity = chromatic_reflectivity * intensity; c.depth = depth - 1; c.kind = 0;
-            tasks[ tsp++ ] = c;
-            intensity *= ( 1.0 - chromatic_reflectivity );
-        }
-
-        /* diffuse reflection :526-630 */
-        if( intensity * diffuse_reflectivity >= min_intensity )
-        {
-            ShadeCtx s;
-            s.diffuse_intensity = intensity * diffuse_reflectivity;
-            s.pos = pos;
-            s.surface_d = v_neg( trans.exit_nor );
-            s.theta_i = acn_acos( -v_mlv( t.d, s.surface_d ) );
-            s.ray_projection = v_of_length( v_orthogonal_projection( t.d, s.surface_d ), 1.0 );
-            s.on_a = on_a; s.on_b = on_b;
-            uint64_t rv = v_random_seed( s.pos, 3294479285ull ) + v_random_seed( s.surface_d, 3247146734ull );
-            V3 Tc = v_mld( T, enter_color );
-
-            const acn_node* light = &sc.nodes[ sc.light_root ];
-            for( int i = 0; i < light->child1; i++ )
-            {
-                int light_idx = sc.elems[ light->child0 + i ];
-                const acn_node* light_src = &sc.nodes[ light_idx ];
-                V3 fov_d; double cos_rs;
-                obj_fov_dev( light_src, pos, &fov_d, &cos_rs );
-                M3 src_con = m_transposed( m_con_z( fov_d ) );
-                double cyl_hgt = 1 - cos_rs;
-                uint64_t direct_samples = ( uint64_t )( sc.prm.direct_samples * s.diffuse_intensity );
-                direct_samples = ( direct_samples == 0 ) ? 1 : direct_samples;
-                double sum = 0;
-                for( uint64_t j = 0; j < direct_samples; j++ )
-                {
-                    sum += direct_sample( sc, s, light_idx, light_src, src_con, cyl_hgt, &rv, cnt );
-                }
-                acc_add( acc, Tc, v_mlf( v_mlf( ld3( light_src->color ), sum ), 2.0 * cyl_hgt / direct_samples ) );
-            }
-
-            if( sc.prm.path_samples && depth > 10 )
-            {
-                if( fsp >= ACN_MAX_PATH_LEVELS ) { cnt->c[ CNT_OVERFLOW ]++; }
-                else
-                {
-                    PathFrame& f = frames[ fsp ];
-                    new_frame = true;
-                    f.s = s;
-                    f.out_con = m_transposed( m_con_z( s.surface_d ) );
-                    uint64_t path_samples = ( uint64_t )( sc.prm.path_samples * s.diffuse_intensity );
-                    path_samples = ( path_samples == 0 ) ? 1 : path_samples;
-                    f.T = v_mlf( Tc, 2.0 / path_samples );
-                    f.rv = rv; f.i = 0; f.n = path_samples; f.depth = depth;
-                }
-            }
-            intensity *= ( 1.0 - diffuse_reflectivity );
-        }
-
-        /* refraction :633-653 */
-        if( transparent && intensity >= min_intensity )
-        {
-            RayTask c;
-            c.p = ray_pos( t.p, t.d, offs + 2.0 * F3_EPS );
-            c.d = fresnel_refraction( t.d, trans.exit_nor, trix );
-            c.T = T; c.intensity = intensity; c.depth = depth - 1; c.kind = 0;
-            tasks[ tsp++ ] = c;
-        }
-
-        /* the path loop of this call runs before the sibling rays pushed above */
-        if( new_frame ) frames[ fsp++ ].task_base = tsp;
-    }
 }
 
 /* vectors.h:372-384 */

@@ -1,0 +1,577 @@
+/* acn_pipeline.h -- the level-synchronous wavefront formulation of scene_s_lum (src/scene.c:420-667) for gfx950.
+ *
+ * The reference evaluates one pixel by a branching recursion: specular chains (Fresnel reflection / chromatic
+ * reflection / refraction, depth-1 each) with, at every diffuse shading point, a direct-light loop over
+ * direct_samples*I cap samples per light and -- while depth > 10 -- a path loop over path_samples*I hemisphere
+ * samples whose hits recurse with depth-10.  Every term is linear in what the recursion returns, so each pending
+ * piece of work carries a colour throughput T and adds T * value into its pixel.  That turns the recursion into
+ * three kinds of records and two kernels that alternate once per path level:
+ *
+ *   k_walk   (one LANE per sample position or per child hit)    primary ray / child hit -> depth-first walk of the
+ *            specular tree with a small per-lane ray stack; light hits and background go straight to the pixel;
+ *            every diffuse shading point becomes a DTask, appended to a size-class queue through a wave
+ *            ballot + prefix (one atomic per wave and class).
+ *   k_shade  (one WAVEFRONT per DTask; 16 / 4 / 1 lanes per task for the small size classes)   lanes = samples:
+ *            lane j jumps the shading point's LCG stream ahead by 2j draws (the reference consumes exactly two
+ *            draws per sample, scene.c:558,598), casts its cap sample at the light, Oren-Nayar weight, shadow ray;
+ *            then the path samples: hemisphere sample, transition hit against matter; misses take the background,
+ *            hits are compacted (ballot + prefix) into the HitRec queue of the next level.
+ *
+ * Scene access: root-compound loops run in lock-step over all lanes, so node records are fetched with wave-uniform
+ * indices (scalar cache -> SGPRs); only rays that enter a CSG envelope go through the per-lane hit machine.
+ *
+ * Pixel accumulation is order-independent and therefore bit-reproducible: contributions are added as 2^-40
+ * fixed-point integers with 64-bit integer atomics (resolution 9.1e-13, contributions clamped to +-65536, far
+ * above the 1.0 at which cl_s_sat saturates).
+ */
+#ifndef ACN_PIPELINE_H
+#define ACN_PIPELINE_H
+
+#include "acn_device.h"
+
+/* ---- LCG jump-ahead: x -> a^(2^K) x + c_K in one step, constants folded at compile time ---- */
+struct LcgStep { uint64_t a, c; };
+
+constexpr LcgStep lcg_pow2( int k )
+{
+    LcgStep s = { ACN_LCG00_A, ACN_LCG00_C };
+    for( int i = 0; i < k; i++ ) { s.c = ( s.a + 1 ) * s.c; s.a = s.a * s.a; }
+    return s;
+}
+
+template< int K > DEV uint64_t lcg_jump_pow2( uint64_t x )
+{
+    constexpr LcgStep s = lcg_pow2( K );
+    return s.a * x + s.c;
+}
+
+/* jump by 2*sub draws for sub < 64 */
+DEV uint64_t lcg_jump_lane( uint64_t x, int sub )
+{
+    if( sub & 1 )  x = lcg_jump_pow2< 1 >( x );
+    if( sub & 2 )  x = lcg_jump_pow2< 2 >( x );
+    if( sub & 4 )  x = lcg_jump_pow2< 3 >( x );
+    if( sub & 8 )  x = lcg_jump_pow2< 4 >( x );
+    if( sub & 16 ) x = lcg_jump_pow2< 5 >( x );
+    if( sub & 32 ) x = lcg_jump_pow2< 6 >( x );
+    return x;
+}
+
+/* ---- fixed-point pixel accumulation ---- */
+#define ACN_FIX_SCALE 1099511627776.0          /* 2^40 */
+#define ACN_FIX_INV   9.094947017729282e-13    /* 2^-40 */
+#define ACN_FIX_CLAMP 65536.0
+
+DEV long long to_fixed( double x )
+{
+    x = x < ACN_FIX_CLAMP ? x : ACN_FIX_CLAMP;
+    x = x > -ACN_FIX_CLAMP ? x : -ACN_FIX_CLAMP;   /* NaN falls through both and converts to 0 below */
+    if( x != x ) return 0;
+    return __double2ll_rn( x * ACN_FIX_SCALE );
+}
+
+DEV void pixel_add( unsigned long long* accum, size_t i, V3 c )
+{
+    long long x = to_fixed( c.x ), y = to_fixed( c.y ), z = to_fixed( c.z );
+    if( x ) atomicAdd( &accum[ i * 3 + 0 ], ( unsigned long long )x );
+    if( y ) atomicAdd( &accum[ i * 3 + 1 ], ( unsigned long long )y );
+    if( z ) atomicAdd( &accum[ i * 3 + 2 ], ( unsigned long long )z );
+}
+
+/* ---- records ---- */
+
+/* pending ray of the specular walk */
+struct RayTask
+{
+    V3 p, d;
+    V3 T;               /* colour throughput applied to whatever this ray returns */
+    double intensity;
+    int depth;
+    int pad;
+};
+
+/* a diffuse shading point whose sample loops are still to run (scene.c:526-621) */
+struct DTask
+{
+    V3 pos;              /* surface.p */
+    V3 surface_d;        /* -exit_nor */
+    V3 ray_projection;
+    double theta_i, on_a, on_b;
+    double diffuse_intensity;
+    V3 Tc;               /* T * obj_color( enter_obj ) */
+    uint64_t rv;         /* seed of the shading point's LCG stream (scene.c:537) */
+    int depth;
+    uint32_t pixel;
+};
+
+/* a path-sample hit: the arguments of the recursive scene_s_lum call of scene.c:610 */
+struct HitRec
+{
+    V3 p, d;
+    double offs;
+    V3 exit_nor;
+    V3 T;
+    double intensity;
+    int exit_obj, enter_obj;
+    int depth;
+    uint32_t pixel;
+};
+
+#define ACN_NCLASS 4
+enum { QC_TASKS = 0, QC_CLASS0 = 1, QC_CHILDREN = 5, QC_FLAGS = 6, QC_N = 8 };
+
+struct Queues
+{
+    DTask*    tasks;
+    uint32_t* idx[ ACN_NCLASS ];    /* per size class: indices into tasks[] */
+    HitRec*   children;
+    uint32_t* counts;               /* QC_* */
+    uint32_t  task_cap, child_cap;
+};
+
+/* lanes per task of the size classes, and the smallest sample count that goes to each */
+DEV int size_class( uint64_t n )
+{
+    return n > 32 ? 0 : n > 8 ? 1 : n > 2 ? 2 : 3;
+}
+
+/* one atomic per wave: every lane with `want` gets a distinct slot */
+DEV uint32_t wave_alloc( uint32_t* counter, bool want )
+{
+    unsigned long long mask = __ballot( want );
+    if( !want ) return 0xFFFFFFFFu;
+    int lane = ( int )( threadIdx.x & 63 );
+    int leader = __builtin_amdgcn_readfirstlane( __ffsll( ( long long )mask ) - 1 );
+    uint32_t base = 0;
+    if( lane == leader ) base = atomicAdd( counter, ( uint32_t )__popcll( mask ) );
+    base = ( uint32_t )__builtin_amdgcn_readlane( ( int )base, leader );
+    return base + ( uint32_t )__popcll( mask & ( ( 1ull << lane ) - 1ull ) );
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* scene_s_lum for one hit, everything except the two sample loops (scene.c:420-537, 623-664).  Specular children
+ * go on the lane's ray stack; the diffuse block becomes a DTask.  Returns false on stack overflow. */
+#ifndef ACN_WALK_STACK
+#define ACN_WALK_STACK 48
+#endif
+
+template< class CT >
+DEV void shade_hit( const DevScene& sc, const Queues& q, V3 rp, V3 rd, double offs, const Trans& trans, int depth,
+                    double intensity, V3 T, uint32_t pixel, RayTask* st, int& sp, V3& acc, CT* cnt )
+{
+    const double min_intensity = sc.prm.trace_min_intensity;
+    if( depth == 0 || intensity < min_intensity ) return;
+    cnt->inc( CNT_LUM );
+    V3 pos = ray_pos( rp, rd, offs );
+    MatP enter_obj = trans.enter_obj >= 0 ? &sc.mats[ trans.enter_obj ] : nullptr;
+    MatP exit_obj  = trans.exit_obj  >= 0 ? &sc.mats[ trans.exit_obj  ] : nullptr;
+
+    if( enter_obj && enter_obj->radiance > 0 )   /* :432-437 */
+    {
+        double diff_sqr = v_diff_sqr( pos, ld3( sc.nodes[ trans.enter_obj ].pos ) );
+        double light_intensity = ( diff_sqr > 0 ) ? ( enter_obj->radiance / diff_sqr ) : F3_MAG;
+        V3 c = v_mlf( ld3( enter_obj->color ), light_intensity * intensity );
+        acc.x += T.x * c.x; acc.y += T.y * c.y; acc.z += T.z * c.z;
+        return;
+    }
+
+    double trix = 1.0;
+    double fresnel_reflectivity = 0, chromatic_reflectivity = 0, diffuse_reflectivity = 0;
+    double on_a = 1.0, on_b = 0.0;
+    bool transparent = false;
+    V3 enter_color = mk( 1, 1, 1 );
+    if( enter_obj )   /* :448-462 */
+    {
+        trix = enter_obj->refractive_index;
+        fresnel_reflectivity   = ( enter_obj->fresnel_reflectivity != 0 && enter_obj->refractive_index != 1.0 ) ? 1.0 : 0.0;
+        chromatic_reflectivity = enter_obj->chromatic_reflectivity;
+        diffuse_reflectivity   = enter_obj->diffuse_reflectivity;
+        transparent            = v_sqr( ld3( enter_obj->transparency ) ) > 0;
+        double sigma           = enter_obj->sigma;
+        if( sigma > 0 )
+        {
+            double sigma_sqr = f_sqr( sigma );
+            on_a = 1.0 - 0.5 * sigma_sqr / ( sigma_sqr + 0.33 );
+            on_b = 0.45 * sigma_sqr / ( sigma_sqr + 0.09 );
+        }
+        enter_color = ld3( enter_obj->color );
+    }
+    if( exit_obj )   /* :464-470 and the absorption of :656-664, which scales everything this call returns */
+    {
+        trix /= exit_obj->refractive_index;
+        fresnel_reflectivity = 1.0;
+        diffuse_reflectivity = chromatic_reflectivity = 0;
+        transparent = true;
+        if( offs > 0 )
+        {
+            T.x *= acn_pow( exit_obj->transparency[ 0 ], offs );
+            T.y *= acn_pow( exit_obj->transparency[ 1 ], offs );
+            T.z *= acn_pow( exit_obj->transparency[ 2 ], offs );
+        }
+    }
+
+    bool room = sp + 3 <= ACN_WALK_STACK;
+    if( !room ) atomicOr( sc.flags, ACN_FLAG_STACK_OVERFLOW );
+
+    /* fresnel reflection :473-495 */
+    if( fresnel_reflectivity > 0 && intensity >= min_intensity )
+    {
+        V3 out_d;
+        double reflectance = fresnel_reflection( rd, trans.exit_nor, trix, &out_d ) * fresnel_reflectivity;
+        if( room )
+        {
+            RayTask& c = st[ sp++ ];
+            c.p = pos; c.d = out_d; c.T = T; c.intensity = reflectance * intensity; c.depth = depth - 1;
+        }
+        intensity *= ( 1.0 - reflectance );
+    }
+
+    /* chromatic reflection :498-523 */
+    if( chromatic_reflectivity > 0 && intensity >= min_intensity )
+    {
+        if( room )
+        {
+            RayTask& c = st[ sp++ ];
+            c.p = pos; c.d = v_reflection( rd, trans.exit_nor ); c.T = v_mld( T, enter_color );
+            c.intensity = chromatic_reflectivity * intensity; c.depth = depth - 1;
+        }
+        intensity *= ( 1.0 - chromatic_reflectivity );
+    }
+
+    /* diffuse reflection :526-537: hand the sample loops to k_shade */
+    bool diffuse = intensity * diffuse_reflectivity >= min_intensity;
+    double diffuse_intensity = intensity * diffuse_reflectivity;
+    uint64_t n_direct = 0, n_path = 0;
+    if( diffuse )
+    {
+        if( sc.nodes[ sc.light_root ].child1 > 0 )
+        {
+            n_direct = ( uint64_t )( sc.prm.direct_samples * diffuse_intensity );
+            n_direct = ( n_direct == 0 ) ? 1 : n_direct;
+        }
+        if( sc.prm.path_samples && depth > 10 )
+        {
+            n_path = ( uint64_t )( sc.prm.path_samples * diffuse_intensity );
+            n_path = ( n_path == 0 ) ? 1 : n_path;
+        }
+    }
+    bool emit = diffuse && ( n_direct | n_path ) != 0;
+    {
+        uint32_t slot = wave_alloc( &q.counts[ QC_TASKS ], emit );
+        bool ok = emit && slot < q.task_cap;
+        if( emit && !ok ) atomicOr( &q.counts[ QC_FLAGS ], ACN_FLAG_TASK_OVERFLOW );
+        int cls = ok ? size_class( n_direct > n_path ? n_direct : n_path ) : -1;
+        if( ok )
+        {
+            DTask& t = q.tasks[ slot ];
+            V3 surface_d = v_neg( trans.exit_nor );
+            t.pos = pos;
+            t.surface_d = surface_d;
+            t.theta_i = acn_acos( -v_mlv( rd, surface_d ) );
+            t.ray_projection = v_of_length( v_orthogonal_projection( rd, surface_d ), 1.0 );
+            t.on_a = on_a; t.on_b = on_b;
+            t.diffuse_intensity = diffuse_intensity;
+            t.Tc = v_mld( T, enter_color );
+            t.rv = v_random_seed( pos, 3294479285ull ) + v_random_seed( surface_d, 3247146734ull );
+            t.depth = depth;
+            t.pixel = pixel;
+        }
+        for( int k = 0; k < ACN_NCLASS; k++ )
+        {
+            uint32_t is = wave_alloc( &q.counts[ QC_CLASS0 + k ], cls == k );
+            if( cls == k ) q.idx[ k ][ is ] = slot;
+        }
+    }
+    if( diffuse ) intensity *= ( 1.0 - diffuse_reflectivity );
+
+    /* refraction :633-653 */
+    if( transparent && intensity >= min_intensity )
+    {
+        if( room )
+        {
+            RayTask& c = st[ sp++ ];
+            c.p = ray_pos( rp, rd, offs + 2.0 * F3_EPS );
+            c.d = fresnel_refraction( rd, trans.exit_nor, trix );
+            c.T = T; c.intensity = intensity; c.depth = depth - 1;
+        }
+    }
+}
+
+/* depth-first walk of the specular tree: pops rays, traces them (scene_s_trans_hit), shades the hits */
+template< class CT >
+DEV void walk_rays( const DevScene& sc, const Queues& q, uint32_t pixel, RayTask* st, int& sp, V3& acc, CT* cnt )
+{
+    const V3 bg = ld3( sc.prm.background_color );
+    while( sp > 0 )
+    {
+        RayTask t = st[ --sp ];
+        Trans trans;
+        trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
+        double offs = scene_trans_hit_dev( sc, t.p, t.d, &trans, cnt );
+        if( !( offs < F3_INF ) )
+        {
+            V3 c = v_mlf( bg, t.intensity );
+            acc.x += t.T.x * c.x; acc.y += t.T.y * c.y; acc.z += t.T.z * c.z;
+            continue;
+        }
+        shade_hit( sc, q, t.p, t.d, offs, trans, t.depth, t.intensity, t.T, pixel, st, sp, acc, cnt );
+    }
+}
+
+DEV void wave_add_counters( unsigned long long* global, const Cnt< true >& mine )
+{
+    for( int k = 0; k < CNT_N; k++ )
+    {
+        unsigned long long v = mine.c[ k ];
+        for( int off = 32; off > 0; off >>= 1 ) v += __shfl_down( v, off, 64 );
+        if( ( threadIdx.x & 63 ) == 0 && v ) atomicAdd( &global[ k ], v );
+    }
+}
+DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
+
+/* level 0: one lane per sample position (lum_machine_s_func, scene.c:976-1011) */
+#ifndef ACN_SHADE_WAVES
+#define ACN_SHADE_WAVES 4
+#endif
+#ifndef ACN_WALK_WAVES
+#define ACN_WALK_WAVES 2
+#endif
+
+/* Kernel parameter convention: every buffer is passed as its own __restrict__ pointer (so that uniform reads of
+ * the read-only ones can go through the scalar cache) and the DevScene / Queues views are rebuilt inside. */
+#define ACN_SCENE_PARAMS  DevScene sc_in, const GNode* __restrict__ p_nodes, const GMat* __restrict__ p_mats, const int32_t* __restrict__ p_elems
+#define ACN_SCENE_ARGS( h ) ( h )->dev, ( h )->d_nodes, ( h )->d_mats, ( h )->d_elems
+#define ACN_SCENE_VIEW    DevScene sc = sc_in; sc.nodes = ( NodeP )p_nodes; sc.mats = ( MatP )p_mats; sc.elems = ( ElemP )p_elems; sc.flags = p_counts + QC_FLAGS;
+
+template< bool COUNT >
+__global__ __launch_bounds__( 256, ACN_WALK_WAVES )
+void k_walk_primary( ACN_SCENE_PARAMS, DTask* __restrict__ p_tasks, uint32_t* __restrict__ p_idx0, uint32_t* __restrict__ p_idx1,
+                     uint32_t* __restrict__ p_idx2, uint32_t* __restrict__ p_idx3, uint32_t* __restrict__ p_counts, uint32_t task_cap,
+                     const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n,
+                     unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
+{
+    ACN_SCENE_VIEW
+    Queues q;
+    q.tasks = p_tasks; q.idx[ 0 ] = p_idx0; q.idx[ 1 ] = p_idx1; q.idx[ 2 ] = p_idx2; q.idx[ 3 ] = p_idx3;
+    q.children = nullptr; q.counts = p_counts; q.task_cap = task_cap; q.child_cap = 0;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    Cnt< COUNT > cnt;
+    cnt.clear();
+    if( i < n )
+    {
+        uint32_t pixel = base + i;
+        double mx, my;
+        if( pos_xy ) { mx = pos_xy[ ( size_t )pixel * 2 ]; my = pos_xy[ ( size_t )pixel * 2 + 1 ]; }
+        else
+        {
+            size_t pix = first_pixel + pixel;
+            mx = ( double )( pix % sc.prm.image_width ) + 0.5;
+            my = ( double )( pix / sc.prm.image_width ) + 0.5;
+        }
+        RayTask st[ ACN_WALK_STACK ];
+        int sp = 0;
+        V3 acc = mk( 0, 0, 0 );
+        RayTask& t = st[ sp++ ];
+        camera_ray( sc, mx, my, &t.p, &t.d );
+        t.T = mk( 1, 1, 1 ); t.intensity = 1.0; t.depth = ( int )sc.prm.trace_depth;
+        walk_rays( sc, q, pixel, st, sp, acc, &cnt );
+        pixel_add( accum, pixel, acc );
+    }
+    wave_add_counters( counters, cnt );
+}
+
+/* level >= 1: one lane per path-sample hit */
+template< bool COUNT >
+__global__ __launch_bounds__( 256, ACN_WALK_WAVES )
+void k_walk_children( ACN_SCENE_PARAMS, DTask* __restrict__ p_tasks, uint32_t* __restrict__ p_idx0, uint32_t* __restrict__ p_idx1,
+                      uint32_t* __restrict__ p_idx2, uint32_t* __restrict__ p_idx3, uint32_t* __restrict__ p_counts, uint32_t task_cap,
+                      const HitRec* __restrict__ recs, uint32_t n,
+                      unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
+{
+    ACN_SCENE_VIEW
+    Queues q;
+    q.tasks = p_tasks; q.idx[ 0 ] = p_idx0; q.idx[ 1 ] = p_idx1; q.idx[ 2 ] = p_idx2; q.idx[ 3 ] = p_idx3;
+    q.children = nullptr; q.counts = p_counts; q.task_cap = task_cap; q.child_cap = 0;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    Cnt< COUNT > cnt;
+    cnt.clear();
+    if( i < n )
+    {
+        HitRec r = recs[ i ];
+        RayTask st[ ACN_WALK_STACK ];
+        int sp = 0;
+        V3 acc = mk( 0, 0, 0 );
+        Trans trans;
+        trans.exit_nor = r.exit_nor; trans.exit_obj = r.exit_obj; trans.enter_obj = r.enter_obj;
+        shade_hit( sc, q, r.p, r.d, r.offs, trans, r.depth, r.intensity, r.T, r.pixel, st, sp, acc, &cnt );
+        walk_rays( sc, q, r.pixel, st, sp, acc, &cnt );
+        pixel_add( accum, r.pixel, acc );
+    }
+    wave_add_counters( counters, cnt );
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* k_shade: the two sample loops of a diffuse shading point, LPT lanes per task */
+
+template< int LPT > DEV double group_sum( double v )
+{
+    for( int off = LPT / 2; off > 0; off >>= 1 ) v += __shfl_xor( v, off, 64 );
+    return v;
+}
+
+template< int LPT > DEV uint64_t lcg_stride( uint64_t x )   /* jump by 2*LPT draws */
+{
+    if( LPT == 64 ) return lcg_jump_pow2< 7 >( x );
+    if( LPT == 16 ) return lcg_jump_pow2< 5 >( x );
+    if( LPT == 4 )  return lcg_jump_pow2< 3 >( x );
+    return lcg_jump_pow2< 1 >( x );
+}
+
+template< int LPT, bool COUNT >
+__global__ __launch_bounds__( 256, ACN_SHADE_WAVES )
+void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t* __restrict__ idx, uint32_t n_tasks,
+              HitRec* __restrict__ p_children, uint32_t child_cap, uint32_t* __restrict__ p_counts,
+              unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
+{
+    ACN_SCENE_VIEW
+    Queues q;
+    q.tasks = nullptr; q.children = p_children; q.counts = p_counts; q.task_cap = 0; q.child_cap = child_cap;
+    constexpr int G = 64 / LPT;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPT;
+    const int grp = lane / LPT;
+    const uint32_t wave = ( blockIdx.x * blockDim.x + threadIdx.x ) >> 6;
+    const uint32_t n_waves = ( gridDim.x * blockDim.x ) >> 6;
+    Cnt< COUNT > cnt;
+    cnt.clear();
+    const V3 bg = ld3( sc.prm.background_color );
+
+    for( uint32_t base = wave * G; base < n_tasks; base += n_waves * G )
+    {
+        uint32_t ti = base + grp;
+        if( ti >= n_tasks ) continue;
+        uint32_t slot = ( ( ElemP )( const void* )idx )[ ti ];
+        if( LPT == 64 ) slot = __builtin_amdgcn_readfirstlane( slot );
+        const DTask ACN_CONST& t = ( ( const DTask ACN_CONST* )tasks )[ slot ];
+        const V3 pos = ldc( t.pos ), surface_d = ldc( t.surface_d ), ray_projection = ldc( t.ray_projection );
+        const double theta_i = t.theta_i, on_a = t.on_a, on_b = t.on_b, diffuse_intensity = t.diffuse_intensity;
+        uint64_t rv = t.rv;
+        V3 lum = mk( 0, 0, 0 );   /* lum_l of scene.c:539, identical in all lanes of the group after each reduction */
+
+        /* ---- direct light, scene.c:542-581 ---- */
+        NodeP light = &sc.nodes[ sc.light_root ];
+        const int n_lights = light->child1;
+        for( int li = 0; li < n_lights; li++ )
+        {
+            int light_idx = __builtin_amdgcn_readfirstlane( sc.elems[ light->child0 + li ] );
+            NodeP light_src = &sc.nodes[ light_idx ];
+            MatP light_mat = &sc.mats[ light_idx ];
+            V3 fov_d; double cos_rs;
+            obj_fov_dev( light_src, pos, &fov_d, &cos_rs );
+            M3 src_con = m_transposed( m_con_z( fov_d ) );
+            double cyl_hgt = 1 - cos_rs;
+            uint64_t direct_samples = ( uint64_t )( sc.prm.direct_samples * diffuse_intensity );
+            direct_samples = ( direct_samples == 0 ) ? 1 : direct_samples;
+            V3 light_pos = ld3( light_src->pos );
+            double radiance = light_mat->radiance;
+
+            double s = 0;
+            uint64_t rvj = lcg_jump_lane( rv, sub );
+            for( uint64_t j = sub; j < direct_samples; j += LPT )
+            {
+                uint64_t r = rvj;
+                rvj = lcg_stride< LPT >( rvj );
+                cnt.inc( CNT_CAP_SAMPLE );
+                V3 out_d = m_mlv( src_con, v_random_sphere_cap( &r, cyl_hgt ) );
+                double weight = v_mlv( out_d, surface_d );
+                if( weight <= 0 ) continue;
+                int ho;
+                double a = element_hit< false >( sc, light_idx, pos, out_d, nullptr, &ho, -F3_INF, &cnt );
+                if( a >= F3_INF ) continue;
+                if( on_b > 0 ) weight = oren_nayar_weight( weight, theta_i, on_a, on_b, out_d, surface_d, ray_projection );
+                cnt.inc( CNT_SHADOW_RAY );
+                if( !root_occluded( sc, sc.matter_root, pos, out_d, a, &cnt ) )
+                {
+                    V3 hit_pos = ray_pos( pos, out_d, a );
+                    double diff_sqr = v_diff_sqr( hit_pos, light_pos );
+                    double local_intensity = ( diff_sqr > 0 ) ? ( radiance / diff_sqr ) : F3_MAG;
+                    s += local_intensity * weight * diffuse_intensity;
+                }
+            }
+            rv = lcg00_jump( rv, 2 * direct_samples );
+            s = group_sum< LPT >( s );
+            double f = s * ( 2.0 * cyl_hgt / direct_samples );
+            lum.x += light_mat->color[ 0 ] * f; lum.y += light_mat->color[ 1 ] * f; lum.z += light_mat->color[ 2 ] * f;
+        }
+
+        /* ---- path tracing, scene.c:584-621 ---- */
+        if( sc.prm.path_samples && t.depth > 10 )
+        {
+            M3 out_con = m_transposed( m_con_z( surface_d ) );
+            uint64_t path_samples = ( uint64_t )( sc.prm.path_samples * diffuse_intensity );
+            path_samples = ( path_samples == 0 ) ? 1 : path_samples;
+            const double norm = 2.0 / path_samples;
+            const V3 Tchild = v_mlf( ldc( t.Tc ), norm );
+            double bsum = 0;
+            uint64_t rvj = lcg_jump_lane( rv, sub );
+            for( uint64_t j = sub; j < path_samples; j += LPT )
+            {
+                uint64_t r = rvj;
+                rvj = lcg_stride< LPT >( rvj );
+                cnt.inc( CNT_CAP_SAMPLE );
+                V3 out_d = m_mlv( out_con, v_random_sphere_cap( &r, 1.0 ) );
+                double weight = v_mlv( out_d, surface_d );
+                bool live = weight > 0;
+                double a = F3_INF;
+                Trans trans;
+                trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
+                if( live )
+                {
+                    if( on_b > 0 ) weight = oren_nayar_weight( weight, theta_i, on_a, on_b, out_d, surface_d, ray_projection );
+                    a = root_trans_hit( sc, sc.matter_root, pos, out_d, &trans, &cnt );
+                }
+                bool hit = live && a < sc.prm.max_path_length;
+                if( live && !hit ) bsum += weight * diffuse_intensity;
+                /* compaction of the surviving path rays into the next level's queue */
+                uint32_t cs = wave_alloc( &q.counts[ QC_CHILDREN ], hit );
+                if( hit )
+                {
+                    if( cs < q.child_cap )
+                    {
+                        HitRec& c = q.children[ cs ];
+                        c.p = pos; c.d = out_d; c.offs = a; c.exit_nor = trans.exit_nor; c.T = Tchild;
+                        c.intensity = weight * diffuse_intensity;
+                        c.exit_obj = trans.exit_obj; c.enter_obj = trans.enter_obj;
+                        c.depth = t.depth - 10; c.pixel = t.pixel;
+                    }
+                    else
+                    {
+                        atomicOr( &q.counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+                    }
+                }
+            }
+            bsum = group_sum< LPT >( bsum ) * norm;
+            lum.x += bg.x * bsum; lum.y += bg.y * bsum; lum.z += bg.z * bsum;
+        }
+
+        if( sub == 0 ) pixel_add( accum, t.pixel, v_mld( ldc( t.Tc ), lum ) );
+    }
+    wave_add_counters( counters, cnt );
+}
+
+/* fixed point -> f64 (+ optional cl_s_sat) for positions [ base, base + n ) */
+__global__ void k_finalize( const unsigned long long* __restrict__ accum, uint32_t n, double gamma, int linear,
+                            double* __restrict__ out_rgb )
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n ) return;
+    V3 c = mk( ( double )( long long )accum[ ( size_t )i * 3 + 0 ] * ACN_FIX_INV,
+               ( double )( long long )accum[ ( size_t )i * 3 + 1 ] * ACN_FIX_INV,
+               ( double )( long long )accum[ ( size_t )i * 3 + 2 ] * ACN_FIX_INV );
+    if( !linear ) c = cl_sat( c, gamma );
+    out_rgb[ ( size_t )i * 3 + 0 ] = c.x;
+    out_rgb[ ( size_t )i * 3 + 1 ] = c.y;
+    out_rgb[ ( size_t )i * 3 + 2 ] = c.z;
+}
+
+#endif /* ACN_PIPELINE_H */

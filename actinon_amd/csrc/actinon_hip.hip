@@ -7,7 +7,7 @@
 #include <string>
 #include <vector>
 
-#include "acn_device.h"
+#include "acn_pipeline.h"
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* error plumbing */
@@ -18,18 +18,29 @@ extern "C" const char* acn_last_error( void ) { return g_last_error.c_str(); }
 #define HIP_TRY( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) \
     return fail( ACN_ERR_DEVICE, std::string( #expr ) + ": " + hipGetErrorString( e_ ) ); } while( 0 )
 
+struct StageEvents { hipEvent_t a, b; int stage; };
+
 struct acn_scene_handle
 {
     int device = 0;
     DevScene dev{};
-    acn_node* d_nodes = nullptr;
-    int32_t*  d_elems = nullptr;
-    Counters* d_counters = nullptr;
+    GNode*   d_nodes = nullptr;
+    GMat*    d_mats = nullptr;
+    int32_t* d_elems = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    uint64_t counters[ 16 ] = { 0 };
     int max_csg_depth = 0;
+    /* workspace of the wavefront pipeline */
+    Queues q{};
+    uint32_t* h_counts = nullptr;              /* pinned */
+    unsigned long long* d_accum = nullptr;  size_t accum_cap = 0;
+    unsigned long long* d_counters = nullptr;
+    std::vector< StageEvents > events;  size_t events_used = 0;
+    bool count_work = false;                   /* ACN_OPT_COUNT_WORK of the current call */
+    uint64_t launches[ 3 ] = { 0, 0, 0 };
+    uint64_t chunks = 0, retries = 0, levels = 0;
+    uint64_t peak_tasks = 0, peak_children = 0;
 };
 
 /* ------------------------------------------------------------------------------------------------------------------ */
@@ -46,47 +57,6 @@ __global__ void k_camera_setup( DevScene sc, M3* out_rot, double* out_unit_f )
     V3 rx = v_mlx( ry, rz );
     M3 r; r.x = rx; r.y = ry; r.z = rz;
     *out_rot = m_transposed( r );
-}
-
-DEV void wave_add_counters( Counters* global, const Counters& mine )
-{
-    for( int k = 0; k < CNT_N; k++ )
-    {
-        unsigned long long v = mine.c[ k ];
-        for( int off = 32; off > 0; off >>= 1 ) v += __shfl_down( v, off, 64 );
-        if( ( threadIdx.x & 63 ) == 0 && v ) atomicAdd( &global->c[ k ], v );
-    }
-}
-
-/* v0: one lane per sample position, serial evaluation (lum_machine_s_func scene.c:956-1013) */
-__global__ __launch_bounds__( 64 )
-void k_render_serial( DevScene sc, const double* __restrict__ pos_xy, size_t first, size_t n, double* __restrict__ out_rgb,
-                      int linear, Counters* counters )
-{
-    size_t i = ( size_t )blockIdx.x * blockDim.x + threadIdx.x;
-    Counters cnt;
-    for( int k = 0; k < CNT_N; k++ ) cnt.c[ k ] = 0;
-    if( i < n )
-    {
-        double mx, my;
-        if( pos_xy ) { mx = pos_xy[ i * 2 ]; my = pos_xy[ i * 2 + 1 ]; }
-        else
-        {
-            size_t pix = first + i;
-            mx = ( double )( pix % sc.prm.image_width ) + 0.5;
-            my = ( double )( pix / sc.prm.image_width ) + 0.5;
-        }
-        RayTask t;
-        camera_ray( sc, mx, my, &t.p, &t.d );
-        t.T = mk( 1, 1, 1 ); t.intensity = 1.0; t.depth = ( int )sc.prm.trace_depth; t.kind = 0;
-        V3 acc = mk( 0, 0, 0 );
-        lum_serial( sc, t, &acc, &cnt );
-        V3 clr = linear ? acc : cl_sat( acc, sc.prm.gamma );
-        out_rgb[ i * 3 + 0 ] = clr.x;
-        out_rgb[ i * 3 + 1 ] = clr.y;
-        out_rgb[ i * 3 + 2 ] = clr.z;
-    }
-    if( counters ) wave_add_counters( counters, cnt );
 }
 
 /* cl_s_sat + cps_from_cl after the (cross-GPU) accumulation */
@@ -109,9 +79,8 @@ __global__ void k_resolve( const double* __restrict__ lin, size_t n, double gamm
 __global__ void k_estimate_envelope( DevScene sc, int node, uint64_t samples, uint32_t rseed, double radius_factor,
                                      V3* scratch, double* out )
 {
-    Counters cnt;
-    for( int k = 0; k < CNT_N; k++ ) cnt.c[ k ] = 0;
-    const acn_node* hdr = &sc.nodes[ node ];
+    Cnt< false > cnt;
+    NodeP hdr = &sc.nodes[ node ];
     uint64_t size = 0;
     V3 sum = mk( 0, 0, 0 );
     uint64_t rv = rseed;
@@ -123,7 +92,7 @@ __global__ void k_estimate_envelope( DevScene sc, int node, uint64_t samples, ui
         double exit_a = F3_INF;
         {
             V3 nor = mk( 0, 0, 0 );
-            double a = obj_ray_hit_dev( sc, node, rp, rd, true, &nor, &cnt );
+            double a = obj_ray_hit_dev( sref( sc ), node, rp, rd, true, &nor, &cnt );
             if( a < F3_INF )
             {
                 V3 lp = rp;
@@ -133,7 +102,7 @@ __global__ void k_estimate_envelope( DevScene sc, int node, uint64_t samples, ui
                     a += F3_EPS * 2;
                     s += a;
                     lp = ray_pos( lp, rd, a );
-                    a = obj_ray_hit_dev( sc, node, lp, rd, true, &nor, &cnt );
+                    a = obj_ray_hit_dev( sref( sc ), node, lp, rd, true, &nor, &cnt );
                 }
                 if( v_mlv( nor, rd ) > 0 ) exit_a = s;
             }
@@ -323,18 +292,50 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     HIP_TRY_H( hipStreamCreate( &h->stream ) );
     HIP_TRY_H( hipEventCreate( &h->ev0 ) );
     HIP_TRY_H( hipEventCreate( &h->ev1 ) );
-    HIP_TRY_H( hipMalloc( &h->d_nodes, sizeof( acn_node ) * scene->n_nodes ) );
+
+    /* ABI layout -> device layout: geometry (GNode) and shading properties (GMat) split */
+    std::vector< GNode > nodes( scene->n_nodes );
+    std::vector< GMat > mats( scene->n_nodes );
+    for( uint32_t i = 0; i < scene->n_nodes; i++ )
+    {
+        const acn_node& a = scene->nodes[ i ];
+        GNode& g = nodes[ i ];
+        memset( &g, 0, sizeof( g ) );
+        g.type = a.type; g.flags = a.flags; g.child0 = a.child0; g.child1 = a.child1;
+        memcpy( g.prm, a.prm, sizeof( g.prm ) );
+        memcpy( g.pos, a.pos, sizeof( g.pos ) );
+        memcpy( g.env_pos, a.env_pos, sizeof( g.env_pos ) );
+        g.env_radius = a.env_radius;
+        memcpy( g.rax, a.rax, sizeof( g.rax ) );
+        g.surface_roughness = a.surface_roughness;
+        g.sdf_kind = a.sdf_kind; g.cycles = a.cycles;
+        GMat& m = mats[ i ];
+        memcpy( m.color, a.color, sizeof( m.color ) );
+        m.radiance = a.radiance; m.refractive_index = a.refractive_index;
+        m.fresnel_reflectivity = a.fresnel_reflectivity; m.chromatic_reflectivity = a.chromatic_reflectivity;
+        m.diffuse_reflectivity = a.diffuse_reflectivity; m.sigma = a.sigma;
+        memcpy( m.transparency, a.transparency, sizeof( m.transparency ) );
+    }
+    HIP_TRY_H( hipMalloc( &h->d_nodes, sizeof( GNode ) * scene->n_nodes ) );
+    HIP_TRY_H( hipMalloc( &h->d_mats, sizeof( GMat ) * scene->n_nodes ) );
     HIP_TRY_H( hipMalloc( &h->d_elems, sizeof( int32_t ) * ( scene->n_elems ? scene->n_elems : 1 ) ) );
-    HIP_TRY_H( hipMalloc( &h->d_counters, sizeof( Counters ) ) );
-    HIP_TRY_H( hipMemcpy( h->d_nodes, scene->nodes, sizeof( acn_node ) * scene->n_nodes, hipMemcpyHostToDevice ) );
+    HIP_TRY_H( hipMalloc( &h->d_counters, sizeof( unsigned long long ) * CNT_N ) );
+    HIP_TRY_H( hipMemset( h->d_counters, 0, sizeof( unsigned long long ) * CNT_N ) );
+    HIP_TRY_H( hipMalloc( &h->q.counts, sizeof( uint32_t ) * QC_N ) );
+    HIP_TRY_H( hipHostMalloc( &h->h_counts, sizeof( uint32_t ) * QC_N ) );
+    HIP_TRY_H( hipMemcpy( h->d_nodes, nodes.data(), sizeof( GNode ) * scene->n_nodes, hipMemcpyHostToDevice ) );
+    HIP_TRY_H( hipMemcpy( h->d_mats, mats.data(), sizeof( GMat ) * scene->n_nodes, hipMemcpyHostToDevice ) );
     if( scene->n_elems ) HIP_TRY_H( hipMemcpy( h->d_elems, scene->elems, sizeof( int32_t ) * scene->n_elems, hipMemcpyHostToDevice ) );
-    h->dev.nodes = h->d_nodes;
-    h->dev.elems = h->d_elems;
+    h->dev.nodes = ( NodeP )h->d_nodes;
+    h->dev.mats = ( MatP )h->d_mats;
+    h->dev.elems = ( ElemP )h->d_elems;
     h->dev.light_root = scene->light_root;
     h->dev.matter_root = scene->matter_root;
     h->dev.n_nodes = scene->n_nodes;
     h->dev.n_elems = scene->n_elems;
     h->dev.prm = scene->params;
+    h->dev.flags = h->q.counts + QC_FLAGS;
+    HIP_TRY_H( hipMemset( h->q.counts, 0, sizeof( uint32_t ) * QC_N ) );
     /* camera basis on the device so that it shares the device's arithmetic */
     {
         M3* d_rot = nullptr; double* d_uf = nullptr;
@@ -351,17 +352,164 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     return ACN_OK;
 }
 
+static void free_workspace( acn_scene_handle* h )
+{
+    if( h->q.tasks ) hipFree( h->q.tasks );
+    for( int k = 0; k < ACN_NCLASS; k++ ) if( h->q.idx[ k ] ) hipFree( h->q.idx[ k ] );
+    if( h->q.children ) hipFree( h->q.children );
+    h->q.tasks = nullptr; h->q.children = nullptr; h->q.task_cap = h->q.child_cap = 0;
+    for( int k = 0; k < ACN_NCLASS; k++ ) h->q.idx[ k ] = nullptr;
+}
+
 extern "C" void acn_scene_free( acn_scene_handle* h )
 {
     if( !h ) return;
     hipSetDevice( h->device );
+    free_workspace( h );
+    if( h->q.counts ) hipFree( h->q.counts );
+    if( h->h_counts ) hipHostFree( h->h_counts );
+    if( h->d_accum ) hipFree( h->d_accum );
     if( h->d_nodes ) hipFree( h->d_nodes );
+    if( h->d_mats ) hipFree( h->d_mats );
     if( h->d_elems ) hipFree( h->d_elems );
     if( h->d_counters ) hipFree( h->d_counters );
+    for( auto& e : h->events ) { hipEventDestroy( e.a ); hipEventDestroy( e.b ); }
     if( h->ev0 ) hipEventDestroy( h->ev0 );
     if( h->ev1 ) hipEventDestroy( h->ev1 );
     if( h->stream ) hipStreamDestroy( h->stream );
     delete h;
+}
+
+/* queue capacities for a call over n positions: enough for every path sample of the largest chunk to hit, bounded
+ * by ACN_WORKSPACE_MB (default 20480) */
+static int ensure_workspace( acn_scene_handle* h, size_t n )
+{
+    size_t budget_mb = 20480;
+    if( const char* e = getenv( "ACN_WORKSPACE_MB" ) ) budget_mb = ( size_t )atoll( e );
+    size_t per_rec = sizeof( HitRec ) + sizeof( DTask ) + ACN_NCLASS * sizeof( uint32_t );
+    size_t max_recs = budget_mb * 1024 * 1024 / per_rec;
+    size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
+    size_t want = n * ( s + 2 ) + 65536;
+    if( want > max_recs ) want = max_recs;
+    if( want < 65536 ) want = 65536;
+    if( want > 0xFFFFFF00ull ) want = 0xFFFFFF00ull;
+    if( h->q.child_cap >= want ) return ACN_OK;
+    free_workspace( h );
+    HIP_TRY( hipMalloc( &h->q.children, sizeof( HitRec ) * want ) );
+    HIP_TRY( hipMalloc( &h->q.tasks, sizeof( DTask ) * want ) );
+    for( int k = 0; k < ACN_NCLASS; k++ ) HIP_TRY( hipMalloc( &h->q.idx[ k ], sizeof( uint32_t ) * want ) );
+    h->q.child_cap = ( uint32_t )want;
+    h->q.task_cap = ( uint32_t )want;
+    return ACN_OK;
+}
+
+static int stage_begin( acn_scene_handle* h, int stage, hipStream_t stream )
+{
+    if( h->events_used == h->events.size() )
+    {
+        StageEvents e{};
+        HIP_TRY( hipEventCreate( &e.a ) );
+        HIP_TRY( hipEventCreate( &e.b ) );
+        h->events.push_back( e );
+    }
+    h->events[ h->events_used ].stage = stage;
+    HIP_TRY( hipEventRecord( h->events[ h->events_used ].a, stream ) );
+    return ACN_OK;
+}
+
+static int stage_end( acn_scene_handle* h, hipStream_t stream )
+{
+    HIP_TRY( hipEventRecord( h->events[ h->events_used ].b, stream ) );
+    h->launches[ h->events[ h->events_used ].stage ]++;
+    h->events_used++;
+    return ACN_OK;
+}
+
+static int read_counts( acn_scene_handle* h, hipStream_t stream )
+{
+    HIP_TRY( hipMemcpyAsync( h->h_counts, h->q.counts, sizeof( uint32_t ) * QC_N, hipMemcpyDeviceToHost, stream ) );
+    HIP_TRY( hipStreamSynchronize( stream ) );
+    return ACN_OK;
+}
+
+template< int LPT >
+static int launch_shade( acn_scene_handle* h, int cls, uint32_t n_tasks, hipStream_t stream )
+{
+    if( n_tasks == 0 ) return ACN_OK;
+    constexpr int G = 64 / LPT;
+    size_t waves = ( ( size_t )n_tasks + G - 1 ) / G;
+    size_t blocks = ( waves + 3 ) / 4;
+    if( blocks > 256 * 32 ) blocks = 256 * 32;
+    int st = stage_begin( h, 1, stream );
+    if( st != ACN_OK ) return st;
+    if( h->count_work )
+        hipLaunchKernelGGL( ( k_shade< LPT, true > ), dim3( ( unsigned )blocks ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                            ( const DTask* )h->q.tasks, ( const uint32_t* )h->q.idx[ cls ], n_tasks, h->q.children, h->q.child_cap,
+                            h->q.counts, h->d_accum, h->d_counters );
+    else
+        hipLaunchKernelGGL( ( k_shade< LPT, false > ), dim3( ( unsigned )blocks ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                            ( const DTask* )h->q.tasks, ( const uint32_t* )h->q.idx[ cls ], n_tasks, h->q.children, h->q.child_cap,
+                            h->q.counts, h->d_accum, h->d_counters );
+    HIP_TRY( hipGetLastError() );
+    return stage_end( h, stream );
+}
+
+/* One chunk of positions [ base, base + cnt ): walk -> ( shade -> walk )* .  Returns 1 if a queue overflowed. */
+static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t first_pixel, uint32_t base, uint32_t cnt,
+                         hipStream_t stream, int* overflow )
+{
+    *overflow = 0;
+    int st;
+    HIP_TRY( hipMemsetAsync( h->q.counts, 0, sizeof( uint32_t ) * QC_N, stream ) );
+    if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
+    if( h->count_work )
+        hipLaunchKernelGGL( k_walk_primary< true >, dim3( ( cnt + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                            h->q.tasks, h->q.idx[ 0 ], h->q.idx[ 1 ], h->q.idx[ 2 ], h->q.idx[ 3 ], h->q.counts, h->q.task_cap,
+                            d_pos_xy, first_pixel, base, cnt, h->d_accum, h->d_counters );
+    else
+        hipLaunchKernelGGL( k_walk_primary< false >, dim3( ( cnt + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                            h->q.tasks, h->q.idx[ 0 ], h->q.idx[ 1 ], h->q.idx[ 2 ], h->q.idx[ 3 ], h->q.counts, h->q.task_cap,
+                            d_pos_xy, first_pixel, base, cnt, h->d_accum, h->d_counters );
+    HIP_TRY( hipGetLastError() );
+    if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
+
+    for( int level = 0; level < ACN_MAX_PATH_LEVELS + 1; level++ )
+    {
+        if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
+        if( h->h_counts[ QC_FLAGS ] & ACN_FLAG_STACK_OVERFLOW ) return fail( ACN_ERR_UNSUPPORTED, "device ray / CSG stack overflow" );
+        if( h->h_counts[ QC_FLAGS ] ) { *overflow = 1; return ACN_OK; }
+        uint32_t n_cls[ ACN_NCLASS ];
+        uint32_t total = 0;
+        for( int k = 0; k < ACN_NCLASS; k++ ) { n_cls[ k ] = h->h_counts[ QC_CLASS0 + k ]; total += n_cls[ k ]; }
+        if( h->h_counts[ QC_TASKS ] > h->peak_tasks ) h->peak_tasks = h->h_counts[ QC_TASKS ];
+        if( total == 0 ) break;
+        h->levels++;
+        HIP_TRY( hipMemsetAsync( h->q.counts + QC_CHILDREN, 0, sizeof( uint32_t ), stream ) );
+        if( ( st = launch_shade< 64 >( h, 0, n_cls[ 0 ], stream ) ) != ACN_OK ) return st;
+        if( ( st = launch_shade< 16 >( h, 1, n_cls[ 1 ], stream ) ) != ACN_OK ) return st;
+        if( ( st = launch_shade< 4 >( h, 2, n_cls[ 2 ], stream ) ) != ACN_OK ) return st;
+        if( ( st = launch_shade< 1 >( h, 3, n_cls[ 3 ], stream ) ) != ACN_OK ) return st;
+        if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
+        if( h->h_counts[ QC_FLAGS ] & ACN_FLAG_STACK_OVERFLOW ) return fail( ACN_ERR_UNSUPPORTED, "device ray / CSG stack overflow" );
+        if( h->h_counts[ QC_FLAGS ] ) { *overflow = 1; return ACN_OK; }
+        uint32_t n_children = h->h_counts[ QC_CHILDREN ];
+        if( n_children > h->peak_children ) h->peak_children = n_children;
+        if( n_children == 0 ) break;
+        /* next level: the task queues are consumed, the child queue feeds the walk */
+        HIP_TRY( hipMemsetAsync( h->q.counts, 0, sizeof( uint32_t ) * QC_CHILDREN, stream ) );
+        if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
+        if( h->count_work )
+            hipLaunchKernelGGL( k_walk_children< true >, dim3( ( n_children + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                                h->q.tasks, h->q.idx[ 0 ], h->q.idx[ 1 ], h->q.idx[ 2 ], h->q.idx[ 3 ], h->q.counts, h->q.task_cap,
+                                ( const HitRec* )h->q.children, n_children, h->d_accum, h->d_counters );
+        else
+            hipLaunchKernelGGL( k_walk_children< false >, dim3( ( n_children + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                                h->q.tasks, h->q.idx[ 0 ], h->q.idx[ 1 ], h->q.idx[ 2 ], h->q.idx[ 3 ], h->q.counts, h->q.task_cap,
+                                ( const HitRec* )h->q.children, n_children, h->d_accum, h->d_counters );
+        HIP_TRY( hipGetLastError() );
+        if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
+    }
+    return ACN_OK;
 }
 
 static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t first, size_t n, double* d_out_rgb,
@@ -369,13 +517,55 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
 {
     if( opts && opts->cancel && *opts->cancel ) return fail( ACN_ERR_CANCELLED, "cancelled" );
     if( n == 0 ) return ACN_OK;
+    if( n > 0xFFFFFF00ull ) return fail( ACN_ERR_ARG, "too many positions in one call" );
     int linear = ( opts && ( opts->flags & ACN_OPT_LINEAR_OUT ) ) ? 1 : 0;
-    HIP_TRY( hipMemsetAsync( h->d_counters, 0, sizeof( Counters ), stream ) );
+    h->count_work = ( opts && ( opts->flags & ACN_OPT_COUNT_WORK ) ) || getenv( "ACN_COUNT_WORK" ) != nullptr;
+    int st = ensure_workspace( h, n );
+    if( st != ACN_OK ) return st;
+    if( h->accum_cap < n )
+    {
+        if( h->d_accum ) hipFree( h->d_accum );
+        h->d_accum = nullptr; h->accum_cap = 0;
+        HIP_TRY( hipMalloc( &h->d_accum, sizeof( unsigned long long ) * 3 * n ) );
+        h->accum_cap = n;
+    }
+    h->events_used = 0;
+    h->launches[ 0 ] = h->launches[ 1 ] = h->launches[ 2 ] = 0;
+    h->chunks = h->retries = h->levels = 0;
+    h->peak_tasks = h->peak_children = 0;
+    HIP_TRY( hipMemsetAsync( h->d_counters, 0, sizeof( unsigned long long ) * CNT_N, stream ) );
     HIP_TRY( hipEventRecord( h->ev0, stream ) );
-    size_t blocks = ( n + 63 ) / 64;
-    hipLaunchKernelGGL( k_render_serial, dim3( ( unsigned )blocks ), dim3( 64 ), 0, stream,
-                        h->dev, d_pos_xy, first, n, d_out_rgb, linear, h->d_counters );
+    HIP_TRY( hipMemsetAsync( h->d_accum, 0, sizeof( unsigned long long ) * 3 * n, stream ) );
+
+    /* chunk so that every path sample of a chunk may survive into the next level's queue */
+    size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
+    size_t chunk = h->q.child_cap / ( s + 2 );
+    if( const char* e = getenv( "ACN_CHUNK" ) ) chunk = ( size_t )atoll( e );
+    if( chunk < 256 ) chunk = 256;
+    size_t base = 0;
+    while( base < n )
+    {
+        if( opts && opts->cancel && *opts->cancel ) return fail( ACN_ERR_CANCELLED, "cancelled" );
+        uint32_t cnt = ( uint32_t )( ( n - base < chunk ) ? n - base : chunk );
+        int overflow = 0;
+        st = render_chunk( h, d_pos_xy, first, ( uint32_t )base, cnt, stream, &overflow );
+        if( st != ACN_OK ) return st;
+        if( overflow )
+        {
+            if( cnt <= 64 ) return fail( ACN_ERR_DEVICE, "work queues overflow even for 64 positions: raise ACN_WORKSPACE_MB" );
+            h->retries++;
+            chunk = cnt / 2;
+            HIP_TRY( hipMemsetAsync( h->d_accum + 3 * base, 0, sizeof( unsigned long long ) * 3 * cnt, stream ) );
+            continue;
+        }
+        h->chunks++;
+        base += cnt;
+    }
+    if( ( st = stage_begin( h, 2, stream ) ) != ACN_OK ) return st;
+    hipLaunchKernelGGL( k_finalize, dim3( ( unsigned )( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, stream,
+                        ( const unsigned long long* )h->d_accum, ( uint32_t )n, h->dev.prm.gamma, linear, d_out_rgb );
     HIP_TRY( hipGetLastError() );
+    if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
     HIP_TRY( hipEventRecord( h->ev1, stream ) );
     h->timed = true;
     return ACN_OK;
@@ -452,13 +642,34 @@ extern "C" int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms )
     return ACN_OK;
 }
 
+extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
+{
+    if( !h || !out || n < 0 || n > 16 || !h->timed ) return fail( ACN_ERR_ARG, "no timed launch" );
+    HIP_TRY( hipSetDevice( h->device ) );
+    HIP_TRY( hipEventSynchronize( h->ev1 ) );
+    double ms[ 3 ] = { 0, 0, 0 };
+    for( size_t i = 0; i < h->events_used; i++ )
+    {
+        float t = 0;
+        HIP_TRY( hipEventElapsedTime( &t, h->events[ i ].a, h->events[ i ].b ) );
+        ms[ h->events[ i ].stage ] += t;
+    }
+    float total = 0;
+    HIP_TRY( hipEventElapsedTime( &total, h->ev0, h->ev1 ) );
+    double v[ 16 ] = { ms[ 0 ], ms[ 1 ], ms[ 2 ], total, ( double )h->launches[ 0 ], ( double )h->launches[ 1 ], ( double )h->launches[ 2 ],
+                       ( double )h->chunks, ( double )h->retries, ( double )h->levels, ( double )h->peak_tasks, ( double )h->peak_children,
+                       ( double )h->q.child_cap, 0, 0, 0 };
+    for( int k = 0; k < n; k++ ) out[ k ] = v[ k ];
+    return ACN_OK;
+}
+
 extern "C" int acn_last_counters( acn_scene_handle* h, uint64_t* out, int n )
 {
     if( !h || !out || n < 0 || n > 16 ) return fail( ACN_ERR_ARG, "bad argument" );
     HIP_TRY( hipSetDevice( h->device ) );
-    Counters c;
-    HIP_TRY( hipMemcpy( &c, h->d_counters, sizeof( c ), hipMemcpyDeviceToHost ) );
-    for( int k = 0; k < n; k++ ) out[ k ] = k < CNT_N ? c.c[ k ] : 0;
+    unsigned long long c[ CNT_N ];
+    HIP_TRY( hipMemcpy( c, h->d_counters, sizeof( c ), hipMemcpyDeviceToHost ) );
+    for( int k = 0; k < n; k++ ) out[ k ] = k < CNT_N ? c[ k ] : 0;
     return ACN_OK;
 }
 

@@ -123,9 +123,10 @@ class Scene:
 class Handle:
     """A flattened scene resident on one GPU (acn_scene_handle)."""
 
-    def __init__(self, flat, device=0):
+    def __init__(self, flat, device=0, count_work=False):
         self.flat = flat
         self.device = device
+        self.count_work = count_work   # instrumented kernels: last_counters() is only meaningful when set
         self.h = C.c_void_p()
         check(hip.acn_scene_upload(C.byref(flat.c), device, C.byref(self.h)), "acn_scene_upload")
 
@@ -139,7 +140,7 @@ class Handle:
 
     def _opts(self, linear, stream):
         o = abi.RenderOpts()
-        o.flags = abi.ACN_OPT_LINEAR_OUT if linear else 0
+        o.flags = (abi.ACN_OPT_LINEAR_OUT if linear else 0) | (abi.ACN_OPT_COUNT_WORK if self.count_work else 0)
         o.stream = stream
         return o
 
@@ -169,6 +170,14 @@ class Handle:
         ms = C.c_double()
         check(hip.acn_last_kernel_ms(self.h, C.byref(ms)), "acn_last_kernel_ms")
         return ms.value
+
+    def last_stages(self):
+        """Per-stage device time (ms) and pipeline statistics of the last render call."""
+        names = ["walk_ms", "shade_ms", "finalize_ms", "total_ms", "walk_launches", "shade_launches", "finalize_launches",
+                 "chunks", "retries", "levels", "peak_tasks", "peak_children", "queue_cap"]
+        buf = (C.c_double * 13)()
+        check(hip.acn_last_stage_ms(self.h, buf, 13), "acn_last_stage_ms")
+        return dict(zip(names, [float(v) for v in buf]))
 
     def last_counters(self):
         names = ["trans_rays", "shadow_rays", "obj_hits", "lum_calls", "cap_samples", "side_calls", "sdf_evals",

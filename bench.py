@@ -176,7 +176,13 @@ def main():
     # kernel duration of the dominant kernel: HIP events recorded by the library on the launch stream
     for _ in range(min(3, max(1, args.steps))):
         step(True)
+    stages = handle.last_stages()
+    # one extra, untimed pass through the instrumented kernels for the work counters
+    handle.count_work = True
+    step(False)
+    torch.cuda.synchronize()
     counters = handle.last_counters()
+    handle.count_work = False
     k_ms = float(np.mean(kernel_ms))
 
     if rank == 0:
@@ -212,6 +218,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_render", "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
                          "note": "path is fp64-VALU bound; HBM roofline reported as BASELINE.json asks"},
+            "stages": stages,
             "work": {"rays_per_step_rank0": counters["trans_rays"] + counters["shadow_rays"],
                      "obj_hit_tests_rank0": counters["obj_hits"],
                      "grays_per_s_rank0": (counters["trans_rays"] + counters["shadow_rays"]) / (k_ms * 1e-3) / 1e9},

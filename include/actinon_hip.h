@@ -128,6 +128,7 @@ typedef struct acn_flat_scene
 /* Render call */
 
 #define ACN_OPT_LINEAR_OUT 1u   /* skip cl_s_sat (src/vectors.h:372-384): caller accumulates / reduces first */
+#define ACN_OPT_COUNT_WORK 2u   /* run the instrumented kernels: acn_last_counters() reports rays / samples / hit tests */
 
 typedef struct acn_render_opts
 {
@@ -163,7 +164,9 @@ int acn_render_positions( acn_scene_handle* h, const double* pos_xy, size_t n, d
                           const acn_render_opts* opts );
 
 /* Same on device-resident buffers (d_pos_xy, d_out_rgb are device pointers on the handle's device).
- * Asynchronous on opts->stream unless that is NULL. */
+ * Work is enqueued on opts->stream (NULL = the handle's own stream, then the call also waits for completion).
+ * The call reads the level queues' fill counts back between path levels, so it synchronises that stream a few
+ * times per call; on return the last kernels may still be in flight on a caller-provided stream. */
 int acn_render_positions_dev( acn_scene_handle* h, const void* d_pos_xy, size_t n, void* d_out_rgb,
                               const acn_render_opts* opts );
 
@@ -180,6 +183,11 @@ int acn_resolve_dev( acn_scene_handle* h, const void* d_linear_rgb, size_t n, vo
 
 /* Timing of the kernels of the last render call on this handle (HIP events on the launch stream), ms. */
 int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms );
+
+/* Per-stage device time of the last render call (HIP events on the launch stream) and pipeline statistics:
+ * out[0] walk kernels ms, [1] shade kernels ms, [2] finalize ms, [3] total ms, [4..6] launches per stage, [7] chunks,
+ * [8] overflow retries, [9] path levels run, [10] peak shading tasks, [11] peak child hits, [12] queue capacity. n <= 16. */
+int acn_last_stage_ms( acn_scene_handle* h, double* out, int n );
 
 /* Work counters of the last render call (rays cast, node visits ...), see DESIGN.md. n <= 16. */
 int acn_last_counters( acn_scene_handle* h, uint64_t* out, int n );
