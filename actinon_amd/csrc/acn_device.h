@@ -494,82 +494,92 @@ DEV int distance_side( NodeP o, V3 pos )   /* objects.c:961-966 */
 }
 
 /* ------------------------------------------------------------------------------------------------------------------ */
-/* side machine: obj_side (objects.c:365-370) over the CSG tree, iteratively. */
+/* side machine: obj_side (objects.c:365-370) over the CSG tree, iteratively.  The innermost composite's frame lives
+ * in registers; the scratch stack is touched only when a composite is nested inside a composite. */
 struct SideFrame { int node; int pc; V3 pos; };
 
 template< class CT >
 DEVN int obj_side_dev( SceneRef sc, int root, V3 pos, CT* cnt )
 {
     SideFrame st[ ACN_CSG_MAX_DEPTH ];
-    int sp = 0;
+    SideFrame cur;
+    cur.node = 0; cur.pc = 0; cur.pos = pos;
+    int depth = 0;
     int node = root;
     int r = 1;
     for( ;; )
     {
-        /* ENTER( node, pos ) */
+        /* EVAL( node, pos ) */
         NodeP n = &sc.nodes[ node ];
         cnt->inc( CNT_SIDE );
-        bool returned = true;
+        bool have = true;
+        int type = n->type;
         if( node_has_env( n ) && env_side( n, pos ) == 1 )
         {
             r = 1;
         }
-        else
+        else if( type <= ACN_DISTANCE )
         {
-            switch( n->type )
+            switch( type )
             {
                 case ACN_PLANE:    r = v_sub_mlv( pos, ld3( n->pos ), ld3( n->rax + 6 ) ) > 0 ? 1 : -1; break;   /* gmath.h:52-55 */
                 case ACN_SPHERE:   r = sphere_observer_side( ld3( n->pos ), n->prm[ 0 ], pos ); break;
                 case ACN_SQUAROID: r = squaroid_side( n, pos ); break;
-                case ACN_DISTANCE: r = distance_side( n, pos ); cnt->inc( CNT_SDF_EVAL ); break;
-                case ACN_PAIR_INSIDE: case ACN_PAIR_OUTSIDE: case ACN_NEG:
-                    if( sp >= ACN_CSG_MAX_DEPTH ) { atomicOr( sc.flags, ACN_FLAG_STACK_OVERFLOW ); r = 1; break; }
-                    st[ sp ].node = node; st[ sp ].pc = 1; st[ sp ].pos = pos; sp++;
-                    node = n->child0;
-                    returned = false;
-                    break;
-                case ACN_SCALE:   /* objects.c:1439-1443 */
-                {
-                    if( sp >= ACN_CSG_MAX_DEPTH ) { atomicOr( sc.flags, ACN_FLAG_STACK_OVERFLOW ); r = 1; break; }
-                    st[ sp ].node = node; st[ sp ].pc = 1; st[ sp ].pos = pos; sp++;
-                    M3 rax = node_rax( n );
-                    V3 p = m_mlv( rax, v_sub( pos, ld3( n->pos ) ) );
-                    pos = v_mld( p, mk( n->prm[ 0 ], n->prm[ 1 ], n->prm[ 2 ] ) );
-                    node = n->child0;
-                    returned = false;
-                    break;
-                }
-                default: r = 1; break;
+                default:           r = distance_side( n, pos ); cnt->inc( CNT_SDF_EVAL ); break;
             }
         }
-        /* RETURN( r ) */
-        while( returned )
+        else if( depth >= ACN_CSG_MAX_DEPTH )
         {
-            if( sp == 0 ) return r;
-            SideFrame& f = st[ sp - 1 ];
-            NodeP fn = &sc.nodes[ f.node ];
-            if( fn->type == ACN_NEG ) { r = -r; sp--; }                                   /* objects.c:1341-1344 */
-            else if( fn->type == ACN_SCALE ) { sp--; }
-            else
+            atomicOr( sc.flags, ACN_FLAG_STACK_OVERFLOW );
+            r = 1;
+        }
+        else
+        {
+            if( depth > 0 ) st[ depth - 1 ] = cur;
+            depth++;
+            cur.node = node; cur.pc = 1; cur.pos = pos;
+            if( type == ACN_SCALE )   /* objects.c:1439-1443 */
             {
-                int want = ( fn->type == ACN_PAIR_INSIDE ) ? -1 : 1;   /* objects.c:1096-1099, 1253-1256 */
-                if( f.pc == 1 )
+                M3 rax = node_rax( n );
+                V3 p = m_mlv( rax, v_sub( pos, ld3( n->pos ) ) );
+                pos = v_mld( p, mk( n->prm[ 0 ], n->prm[ 1 ], n->prm[ 2 ] ) );
+            }
+            node = n->child0;
+            have = false;
+        }
+        /* RETURN( r ) into the enclosing composites */
+        while( have )
+        {
+            if( depth == 0 ) return r;
+            NodeP fn = &sc.nodes[ cur.node ];
+            int ftype = fn->type;
+            bool done = true;
+            if( ftype == ACN_NEG ) r = -r;                                   /* objects.c:1341-1344 */
+            else if( ftype != ACN_SCALE )
+            {
+                int want = ( ftype == ACN_PAIR_INSIDE ) ? -1 : 1;           /* objects.c:1096-1099, 1253-1256 */
+                if( cur.pc == 1 )
                 {
-                    if( r != want ) { r = -want; sp--; }
-                    else { f.pc = 2; node = fn->child1; pos = f.pos; returned = false; }
+                    if( r != want ) r = -want;
+                    else { cur.pc = 2; node = fn->child1; pos = cur.pos; done = false; have = false; }
                 }
                 else
                 {
                     r = ( r == want ) ? want : -want;
-                    sp--;
                 }
+            }
+            if( done )
+            {
+                depth--;
+                if( depth > 0 ) cur = st[ depth - 1 ];
             }
         }
     }
 }
 
 /* ------------------------------------------------------------------------------------------------------------------ */
-/* hit machine: obj_ray_hit (objects.c:261-284) with pair / neg / scale recursion unrolled into frames. */
+/* hit machine: obj_ray_hit (objects.c:261-284) with pair / neg / scale recursion unrolled into frames; same
+ * register-resident innermost frame. */
 struct HitFrame
 {
     int node; short pc; short swapped;
@@ -595,84 +605,81 @@ DEV V3 roughness_normal( NodeP hdr, V3 n, V3 hit_pos )   /* objects.c:267-282 */
 template< class CT >
 DEVN double obj_ray_hit_dev( SceneRef sc, int root, V3 rp, V3 rd, bool want_nor, V3* out_nor, CT* cnt )
 {
-    /* fast path: a leaf needs no frame */
     HitFrame st[ ACN_CSG_MAX_DEPTH ];
-    int sp = 0;
+    HitFrame cur;
+    cur.node = 0; cur.pc = 0; cur.swapped = 0; cur.a1 = 0; cur.offs = 0; cur.n1 = mk( 0, 0, 0 ); cur.rp = rp;
+    int depth = 0;
     int node = root;
     double ret_a = F3_INF;
     V3 ret_n = mk( 0, 0, 0 );
     for( ;; )
     {
-        /* ---- ENTER( node, rp, rd ) ---- */
+        /* ---- EVAL( node, rp, rd ) ---- */
         NodeP n = &sc.nodes[ node ];
         cnt->inc( CNT_OBJ_HIT );
-        bool returned = true;   /* false: a child call was issued */
+        bool have = true;
+        int type = n->type;
         if( node_has_env( n ) && !env_ray_hits( n, rp, rd ) )
         {
             ret_a = F3_INF;
         }
-        else
+        else if( type <= ACN_DISTANCE )
         {
-            switch( n->type )
+            switch( type )
             {
                 case ACN_PLANE:    ret_a = plane_ray_hit( ld3( n->pos ), ld3( n->rax + 6 ), rp, rd, want_nor, &ret_n ); break;
                 case ACN_SPHERE:   ret_a = sphere_ray_hit( ld3( n->pos ), n->prm[ 0 ], rp, rd, want_nor, &ret_n ); break;
                 case ACN_SQUAROID: ret_a = squaroid_ray_hit( n, rp, rd, want_nor, &ret_n ); break;
-                case ACN_DISTANCE: ret_a = distance_ray_hit( n, rp, rd, want_nor, &ret_n, cnt ); break;
-                case ACN_PAIR_INSIDE: case ACN_PAIR_OUTSIDE: case ACN_NEG:
-                    if( sp >= ACN_CSG_MAX_DEPTH ) { atomicOr( sc.flags, ACN_FLAG_STACK_OVERFLOW ); ret_a = F3_INF; break; }
-                    st[ sp ].node = node; st[ sp ].pc = 1; st[ sp ].swapped = 0; st[ sp ].rp = rp; sp++;
-                    node = n->child0;
-                    returned = false;
-                    break;
-                case ACN_SCALE:   /* objects.c:1418-1428 */
-                {
-                    if( sp >= ACN_CSG_MAX_DEPTH ) { atomicOr( sc.flags, ACN_FLAG_STACK_OVERFLOW ); ret_a = F3_INF; break; }
-                    M3 rax = node_rax( n );
-                    V3 inv_scale = mk( n->prm[ 0 ], n->prm[ 1 ], n->prm[ 2 ] );
-                    V3 p2 = v_mld( m_mlv( rax, v_sub( rp, ld3( n->pos ) ) ), inv_scale );
-                    V3 d2 = v_mld( m_mlv( rax, rd ), inv_scale );
-                    double d_length = acn_sqrt( v_sqr( d2 ) );
-                    double d_factor = ( d_length > 0 ) ? ( 1.0 / d_length ) : 0;
-                    d2 = v_mlf( d2, d_factor );
-                    st[ sp ].node = node; st[ sp ].pc = 1; st[ sp ].rp = rp; st[ sp ].n1 = rd; st[ sp ].a1 = d_factor; sp++;
-                    rp = p2; rd = d2;
-                    node = n->child0;
-                    returned = false;
-                    break;
-                }
-                default: ret_a = F3_INF; break;
+                default:           ret_a = distance_ray_hit( n, rp, rd, want_nor, &ret_n, cnt ); break;
             }
+            if( want_nor && ret_a < F3_INF && n->surface_roughness > 0 ) ret_n = roughness_normal( n, ret_n, ray_pos( rp, rd, ret_a ) );
+        }
+        else if( depth >= ACN_CSG_MAX_DEPTH )
+        {
+            atomicOr( sc.flags, ACN_FLAG_STACK_OVERFLOW );
+            ret_a = F3_INF;
+        }
+        else
+        {
+            if( depth > 0 ) st[ depth - 1 ] = cur;
+            depth++;
+            cur.node = node; cur.pc = 1; cur.swapped = 0; cur.rp = rp;
+            if( type == ACN_SCALE )   /* objects.c:1418-1428 */
+            {
+                M3 rax = node_rax( n );
+                V3 inv_scale = mk( n->prm[ 0 ], n->prm[ 1 ], n->prm[ 2 ] );
+                V3 p2 = v_mld( m_mlv( rax, v_sub( rp, ld3( n->pos ) ) ), inv_scale );
+                V3 d2 = v_mld( m_mlv( rax, rd ), inv_scale );
+                double d_length = acn_sqrt( v_sqr( d2 ) );
+                double d_factor = ( d_length > 0 ) ? ( 1.0 / d_length ) : 0;
+                d2 = v_mlf( d2, d_factor );
+                cur.n1 = rd; cur.a1 = d_factor;
+                rp = p2; rd = d2;
+            }
+            node = n->child0;
+            have = false;
         }
 
-        /* ---- POST + RETURN: unwind while results are final ---- */
-        while( returned )
+        /* ---- RETURN( ret_a, ret_n ) into the enclosing composites ---- */
+        while( have )
         {
-            /* POST of `node` called with ( rp, rd ): roughness, objects.c:266-282 */
-            {
-                NodeP hdr = &sc.nodes[ node ];
-                if( want_nor && ret_a < F3_INF && hdr->surface_roughness > 0 )
-                {
-                    ret_n = roughness_normal( hdr, ret_n, ray_pos( rp, rd, ret_a ) );
-                }
-            }
-            if( sp == 0 )
+            if( depth == 0 )
             {
                 /* like the reference, the caller's normal is only written on a hit (obj_ray_exit relies on it) */
                 if( want_nor && ret_a < F3_INF ) *out_nor = ret_n;
                 return ret_a;
             }
-            HitFrame& f = st[ sp - 1 ];
-            NodeP fn = &sc.nodes[ f.node ];
-            if( fn->type == ACN_NEG )   /* objects.c:1329-1339 */
+            NodeP fn = &sc.nodes[ cur.node ];
+            int ftype = fn->type;
+            bool done = true;
+            if( ftype == ACN_NEG )   /* objects.c:1329-1339 */
             {
                 if( ret_a < F3_INF ) ret_n = v_neg( ret_n );
-                node = f.node; rp = f.rp; sp--;
             }
-            else if( fn->type == ACN_SCALE )   /* objects.c:1430-1437 */
+            else if( ftype == ACN_SCALE )   /* objects.c:1430-1437 */
             {
                 double a1 = ret_a + F3_EPS;
-                rd = f.n1;
+                rd = cur.n1;
                 if( a1 < F3_INF )
                 {
                     if( want_nor )
@@ -680,46 +687,42 @@ DEVN double obj_ray_hit_dev( SceneRef sc, int root, V3 rp, V3 rd, bool want_nor,
                         V3 n1 = v_mld( ret_n, mk( fn->prm[ 0 ], fn->prm[ 1 ], fn->prm[ 2 ] ) );
                         ret_n = v_of_length( m_tmlv( node_rax( fn ), n1 ), 1.0 );
                     }
-                    ret_a = a1 * f.a1 - F3_EPS;
+                    ret_a = a1 * cur.a1 - F3_EPS;
                 }
                 else
                 {
                     ret_a = F3_INF;
                 }
-                node = f.node; rp = f.rp; sp--;
             }
             else   /* pair: objects.c:1052-1094 / 1209-1251 */
             {
-                int want = ( fn->type == ACN_PAIR_INSIDE ) ? -1 : 1;
-                if( f.pc == 1 )
+                int want = ( ftype == ACN_PAIR_INSIDE ) ? -1 : 1;
+                if( cur.pc == 1 )
                 {
-                    f.a1 = ret_a; f.n1 = ret_n; f.pc = 2;
-                    node = fn->child1; rp = f.rp;
-                    returned = false;
+                    cur.a1 = ret_a; cur.n1 = ret_n; cur.pc = 2;
+                    node = fn->child1; rp = cur.rp;
+                    done = false; have = false;
                 }
-                else if( f.pc == 2 )
+                else if( cur.pc == 2 )
                 {
-                    double a1 = f.a1, a2 = ret_a;
-                    if( a1 < a2 && obj_side_dev( sc, fn->child1, ray_pos( f.rp, rd, a1 ), cnt ) == want )
+                    double a1 = cur.a1, a2 = ret_a;
+                    if( a1 < a2 && obj_side_dev( sc, fn->child1, ray_pos( cur.rp, rd, a1 ), cnt ) == want )
                     {
-                        ret_a = a1; ret_n = f.n1;
-                        node = f.node; rp = f.rp; sp--;
+                        ret_a = a1; ret_n = cur.n1;
                     }
                     else if( a2 >= F3_INF )
                     {
                         ret_a = F3_INF;
-                        node = f.node; rp = f.rp; sp--;
                     }
-                    else if( obj_side_dev( sc, fn->child0, ray_pos( f.rp, rd, a2 ), cnt ) == want )
+                    else if( obj_side_dev( sc, fn->child0, ray_pos( cur.rp, rd, a2 ), cnt ) == want )
                     {
                         /* ret_a = a2, ret_n = n2 already */
-                        node = f.node; rp = f.rp; sp--;
                     }
                     else
                     {
-                        f.offs = a2; f.swapped = 0; f.pc = 3;
-                        node = fn->child0; rp = ray_pos( f.rp, rd, f.offs );
-                        returned = false;
+                        cur.offs = a2; cur.swapped = 0; cur.pc = 3;
+                        node = fn->child0; rp = ray_pos( cur.rp, rd, cur.offs );
+                        done = false; have = false;
                     }
                 }
                 else
@@ -728,35 +731,40 @@ DEVN double obj_ray_hit_dev( SceneRef sc, int root, V3 rp, V3 rd, bool want_nor,
                     if( a >= F3_INF )
                     {
                         ret_a = F3_INF;
-                        node = f.node; rp = f.rp; sp--;
                     }
                     else
                     {
-                        V3 walk_p = ray_pos( f.rp, rd, f.offs );
-                        int obj2 = f.swapped ? fn->child0 : fn->child1;
+                        V3 walk_p = ray_pos( cur.rp, rd, cur.offs );
+                        int obj2 = cur.swapped ? fn->child0 : fn->child1;
                         if( obj_side_dev( sc, obj2, ray_pos( walk_p, rd, a ), cnt ) == want )
                         {
-                            ret_a = f.offs + a;   /* ret_n = n1 of the last child call */
-                            node = f.node; rp = f.rp; sp--;
+                            ret_a = cur.offs + a;   /* ret_n = n1 of the last child call */
                         }
                         else
                         {
-                            f.offs += a + 2 * F3_EPS;
-                            if( !( f.offs < F3_INF ) )
+                            cur.offs += a + 2 * F3_EPS;
+                            if( !( cur.offs < F3_INF ) )
                             {
                                 ret_a = F3_INF;
-                                node = f.node; rp = f.rp; sp--;
                             }
                             else
                             {
-                                f.swapped ^= 1;
-                                node = f.swapped ? fn->child1 : fn->child0;
-                                rp = ray_pos( f.rp, rd, f.offs );
-                                returned = false;
+                                cur.swapped ^= 1;
+                                node = cur.swapped ? fn->child1 : fn->child0;
+                                rp = ray_pos( cur.rp, rd, cur.offs );
+                                done = false; have = false;
                             }
                         }
                     }
                 }
+            }
+            if( done )
+            {
+                /* POST of the composite itself (objects.c:266-282), then hand its result to its parent */
+                rp = cur.rp;
+                if( want_nor && ret_a < F3_INF && fn->surface_roughness > 0 ) ret_n = roughness_normal( fn, ret_n, ray_pos( rp, rd, ret_a ) );
+                depth--;
+                if( depth > 0 ) cur = st[ depth - 1 ];
             }
         }
     }
@@ -884,6 +892,101 @@ DEV double root_trans_hit( const DevScene& sc, int cmp, V3 rp, V3 rd, Trans* tra
             }
         }
     }
+    return min_a;
+}
+
+/* ---- fast-path forms for k_shade: leaf root elements are tested inline; a ray that gets inside the envelope of a
+ * root element that needs the machine (CSG, SDF, nested compound) is reported as `hard` and handed to the hard-ray
+ * kernels, which redo the query with the full traversal.  The results are identical: an occlusion test is an OR over
+ * the elements, and a transition hit is only computed here when every machine element was missed at its envelope
+ * (obj_ray_hit then returns f3_inf for it, objects.c:264). ---- */
+DEV bool is_fast_type( int type ) { return type >= ACN_PLANE && type <= ACN_SQUAROID; }
+
+template< bool NOR, class CT >
+DEV double leaf_element_hit( NodeP n, int type, V3 rp, V3 rd, V3* nor, CT* cnt )
+{
+    cnt->inc( CNT_OBJ_HIT );
+    if( node_has_env( n ) && !env_ray_hits( n, rp, rd ) ) return F3_INF;
+    double a;
+    if( type == ACN_PLANE )       a = plane_ray_hit( ld3( n->pos ), ld3( n->rax + 6 ), rp, rd, NOR, nor );
+    else if( type == ACN_SPHERE ) a = sphere_ray_hit( ld3( n->pos ), n->prm[ 0 ], rp, rd, NOR, nor );
+    else                          a = squaroid_ray_hit( n, rp, rd, NOR, nor );
+    if( NOR && a < F3_INF && n->surface_roughness > 0 ) *nor = roughness_normal( n, *nor, ray_pos( rp, rd, a ) );
+    return a;
+}
+
+/* 0: not occluded, 1: occluded, 2: undecided (hard) */
+template< class CT >
+DEV int root_occluded_fast( const DevScene& sc, int cmp, V3 rp, V3 rd, double limit, CT* cnt )
+{
+    NodeP o = &sc.nodes[ cmp ];
+    if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) return 0;
+    int first = o->child0, count = o->child1;
+    bool hard = false;
+    for( int i = 0; i < count; i++ )
+    {
+        int element = __builtin_amdgcn_readfirstlane( sc.elems[ first + i ] );
+        NodeP n = &sc.nodes[ element ];
+        int type = n->type;
+        if( is_fast_type( type ) )
+        {
+            double a = leaf_element_hit< false >( n, type, rp, rd, nullptr, cnt );
+            if( a <= limit ) return 1;
+        }
+        else if( !node_has_env( n ) || env_ray_hits( n, rp, rd ) )
+        {
+            hard = true;
+        }
+    }
+    return hard ? 2 : 0;
+}
+
+/* compound_s_ray_trans_hit on a root compound; *hard is set when the query must be redone by the full traversal */
+template< class CT >
+DEV double root_trans_hit_fast( const DevScene& sc, int cmp, V3 rp, V3 rd, Trans* trans, bool* hard, CT* cnt )
+{
+    NodeP o = &sc.nodes[ cmp ];
+    *hard = false;
+    if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) { cnt->inc( CNT_TRANS_RAY ); return F3_INF; }
+    double min_a = F3_INF;
+    int first = o->child0, count = o->child1;
+    bool h = false;
+    for( int i = 0; i < count; i++ )
+    {
+        int element = __builtin_amdgcn_readfirstlane( sc.elems[ first + i ] );
+        NodeP n = &sc.nodes[ element ];
+        int type = n->type;
+        if( !is_fast_type( type ) )
+        {
+            if( !node_has_env( n ) || env_ray_hits( n, rp, rd ) ) h = true;
+            continue;
+        }
+        V3 nor = mk( 0, 0, 0 );
+        double a = leaf_element_hit< true >( n, type, rp, rd, &nor, cnt );
+        if( a < F3_INF )
+        {
+            if( a < min_a - F3_EPS )
+            {
+                min_a = a;
+                if( v_mlv( nor, rd ) > 0 )
+                {
+                    trans->exit_nor = nor; trans->exit_obj = element; trans->enter_obj = -1;
+                }
+                else
+                {
+                    trans->exit_nor = v_neg( nor ); trans->exit_obj = -1; trans->enter_obj = element;
+                }
+            }
+            else if( f_abs( a - min_a ) < F3_EPS )
+            {
+                min_a = a < min_a ? a : min_a;
+                if( v_mlv( nor, rd ) > 0 ) trans->exit_obj = element;
+                else                       trans->enter_obj = element;
+            }
+        }
+    }
+    *hard = h;
+    if( !h ) cnt->inc( CNT_TRANS_RAY );
     return min_a;
 }
 

@@ -87,7 +87,7 @@ struct RayTask
     V3 T;               /* colour throughput applied to whatever this ray returns */
     double intensity;
     int depth;
-    int pad;
+    uint32_t pixel;
 };
 
 /* a diffuse shading point whose sample loops are still to run (scene.c:526-621) */
@@ -117,16 +117,38 @@ struct HitRec
     uint32_t pixel;
 };
 
+/* a shadow ray of k_shade that entered the envelope of a CSG / SDF / compound element: finished by k_hard_shadow */
+struct HardShadow
+{
+    V3 pos, d;
+    double limit;        /* distance of the light hit */
+    V3 contrib;          /* what the sample adds to the pixel if it is not occluded */
+    uint32_t pixel, pad;
+};
+
+/* a path ray of k_shade that did: k_hard_path finishes the transition hit */
+struct HardPath
+{
+    V3 pos, d;
+    V3 T;
+    double intensity;
+    int depth;
+    uint32_t pixel;
+};
+
 #define ACN_NCLASS 4
-enum { QC_TASKS = 0, QC_CLASS0 = 1, QC_CHILDREN = 5, QC_FLAGS = 6, QC_N = 8 };
+enum { QC_TASKS = 0, QC_CLASS0 = 1, QC_CHILDREN = 5, QC_FLAGS = 6, QC_HARD_SHADOW = 7, QC_HARD_PATH = 8, QC_RAYS = 9, QC_N = 12 };
 
 struct Queues
 {
     DTask*    tasks;
     uint32_t* idx[ ACN_NCLASS ];    /* per size class: indices into tasks[] */
     HitRec*   children;
+    HardShadow* hard_shadow;
+    HardPath*   hard_path;
+    RayTask*    rays_out;           /* specular rays spawned by this pass, traced by the next one */
     uint32_t* counts;               /* QC_* */
-    uint32_t  task_cap, child_cap;
+    uint32_t  task_cap, child_cap, hard_cap, ray_cap;
 };
 
 /* lanes per task of the size classes, and the smallest sample count that goes to each */
@@ -150,29 +172,44 @@ DEV uint32_t wave_alloc( uint32_t* counter, bool want )
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* scene_s_lum for one hit, everything except the two sample loops (scene.c:420-537, 623-664).  Specular children
- * go on the lane's ray stack; the diffuse block becomes a DTask.  Returns false on stack overflow. */
-#ifndef ACN_WALK_STACK
-#define ACN_WALK_STACK 48
-#endif
+ * (Fresnel reflection, chromatic reflection, refraction) are appended to the ray queue of the next pass; the diffuse
+ * block becomes a DTask. */
+DEV void push_ray( const Queues& q, bool want, V3 p, V3 d, V3 T, double intensity, int depth, uint32_t pixel )
+{
+    uint32_t slot = wave_alloc( &q.counts[ QC_RAYS ], want );
+    if( want )
+    {
+        if( slot < q.ray_cap )
+        {
+            RayTask& c = q.rays_out[ slot ];
+            c.p = p; c.d = d; c.T = T; c.intensity = intensity; c.depth = depth; c.pixel = pixel;
+        }
+        else
+        {
+            atomicOr( &q.counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+        }
+    }
+}
 
 template< class CT >
 DEV void shade_hit( const DevScene& sc, const Queues& q, V3 rp, V3 rd, double offs, const Trans& trans, int depth,
-                    double intensity, V3 T, uint32_t pixel, RayTask* st, int& sp, V3& acc, CT* cnt )
+                    double intensity, V3 T, uint32_t pixel, V3& acc, CT* cnt )
 {
     const double min_intensity = sc.prm.trace_min_intensity;
-    if( depth == 0 || intensity < min_intensity ) return;
-    cnt->inc( CNT_LUM );
+    /* every lane takes part in the queue appends below; `go` masks the ones with nothing to shade */
+    bool go = !( depth == 0 || intensity < min_intensity );
+    if( go ) cnt->inc( CNT_LUM );
     V3 pos = ray_pos( rp, rd, offs );
-    MatP enter_obj = trans.enter_obj >= 0 ? &sc.mats[ trans.enter_obj ] : nullptr;
-    MatP exit_obj  = trans.exit_obj  >= 0 ? &sc.mats[ trans.exit_obj  ] : nullptr;
+    MatP enter_obj = ( go && trans.enter_obj >= 0 ) ? &sc.mats[ trans.enter_obj ] : nullptr;
+    MatP exit_obj  = ( go && trans.exit_obj  >= 0 ) ? &sc.mats[ trans.exit_obj  ] : nullptr;
 
-    if( enter_obj && enter_obj->radiance > 0 )   /* :432-437 */
+    if( go && enter_obj && enter_obj->radiance > 0 )   /* :432-437 */
     {
         double diff_sqr = v_diff_sqr( pos, ld3( sc.nodes[ trans.enter_obj ].pos ) );
         double light_intensity = ( diff_sqr > 0 ) ? ( enter_obj->radiance / diff_sqr ) : F3_MAG;
         V3 c = v_mlf( ld3( enter_obj->color ), light_intensity * intensity );
         acc.x += T.x * c.x; acc.y += T.y * c.y; acc.z += T.z * c.z;
-        return;
+        go = false;
     }
 
     double trix = 1.0;
@@ -180,7 +217,7 @@ DEV void shade_hit( const DevScene& sc, const Queues& q, V3 rp, V3 rd, double of
     double on_a = 1.0, on_b = 0.0;
     bool transparent = false;
     V3 enter_color = mk( 1, 1, 1 );
-    if( enter_obj )   /* :448-462 */
+    if( go && enter_obj )   /* :448-462 */
     {
         trix = enter_obj->refractive_index;
         fresnel_reflectivity   = ( enter_obj->fresnel_reflectivity != 0 && enter_obj->refractive_index != 1.0 ) ? 1.0 : 0.0;
@@ -196,7 +233,7 @@ DEV void shade_hit( const DevScene& sc, const Queues& q, V3 rp, V3 rd, double of
         }
         enter_color = ld3( enter_obj->color );
     }
-    if( exit_obj )   /* :464-470 and the absorption of :656-664, which scales everything this call returns */
+    if( go && exit_obj )   /* :464-470 and the absorption of :656-664, which scales everything this call returns */
     {
         trix /= exit_obj->refractive_index;
         fresnel_reflectivity = 1.0;
@@ -210,36 +247,27 @@ DEV void shade_hit( const DevScene& sc, const Queues& q, V3 rp, V3 rd, double of
         }
     }
 
-    bool room = sp + 3 <= ACN_WALK_STACK;
-    if( !room ) atomicOr( sc.flags, ACN_FLAG_STACK_OVERFLOW );
-
     /* fresnel reflection :473-495 */
-    if( fresnel_reflectivity > 0 && intensity >= min_intensity )
     {
-        V3 out_d;
-        double reflectance = fresnel_reflection( rd, trans.exit_nor, trix, &out_d ) * fresnel_reflectivity;
-        if( room )
-        {
-            RayTask& c = st[ sp++ ];
-            c.p = pos; c.d = out_d; c.T = T; c.intensity = reflectance * intensity; c.depth = depth - 1;
-        }
-        intensity *= ( 1.0 - reflectance );
+        bool f = go && fresnel_reflectivity > 0 && intensity >= min_intensity;
+        V3 out_d = rd;
+        double reflectance = 0;
+        if( f ) reflectance = fresnel_reflection( rd, trans.exit_nor, trix, &out_d ) * fresnel_reflectivity;
+        push_ray( q, f, pos, out_d, T, reflectance * intensity, depth - 1, pixel );
+        if( f ) intensity *= ( 1.0 - reflectance );
     }
 
     /* chromatic reflection :498-523 */
-    if( chromatic_reflectivity > 0 && intensity >= min_intensity )
     {
-        if( room )
-        {
-            RayTask& c = st[ sp++ ];
-            c.p = pos; c.d = v_reflection( rd, trans.exit_nor ); c.T = v_mld( T, enter_color );
-            c.intensity = chromatic_reflectivity * intensity; c.depth = depth - 1;
-        }
-        intensity *= ( 1.0 - chromatic_reflectivity );
+        bool f = go && chromatic_reflectivity > 0 && intensity >= min_intensity;
+        V3 out_d = rd;
+        if( f ) out_d = v_reflection( rd, trans.exit_nor );
+        push_ray( q, f, pos, out_d, v_mld( T, enter_color ), chromatic_reflectivity * intensity, depth - 1, pixel );
+        if( f ) intensity *= ( 1.0 - chromatic_reflectivity );
     }
 
     /* diffuse reflection :526-537: hand the sample loops to k_shade */
-    bool diffuse = intensity * diffuse_reflectivity >= min_intensity;
+    bool diffuse = go && intensity * diffuse_reflectivity >= min_intensity;
     double diffuse_intensity = intensity * diffuse_reflectivity;
     uint64_t n_direct = 0, n_path = 0;
     if( diffuse )
@@ -285,36 +313,11 @@ DEV void shade_hit( const DevScene& sc, const Queues& q, V3 rp, V3 rd, double of
     if( diffuse ) intensity *= ( 1.0 - diffuse_reflectivity );
 
     /* refraction :633-653 */
-    if( transparent && intensity >= min_intensity )
     {
-        if( room )
-        {
-            RayTask& c = st[ sp++ ];
-            c.p = ray_pos( rp, rd, offs + 2.0 * F3_EPS );
-            c.d = fresnel_refraction( rd, trans.exit_nor, trix );
-            c.T = T; c.intensity = intensity; c.depth = depth - 1;
-        }
-    }
-}
-
-/* depth-first walk of the specular tree: pops rays, traces them (scene_s_trans_hit), shades the hits */
-template< class CT >
-DEV void walk_rays( const DevScene& sc, const Queues& q, uint32_t pixel, RayTask* st, int& sp, V3& acc, CT* cnt )
-{
-    const V3 bg = ld3( sc.prm.background_color );
-    while( sp > 0 )
-    {
-        RayTask t = st[ --sp ];
-        Trans trans;
-        trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
-        double offs = scene_trans_hit_dev( sc, t.p, t.d, &trans, cnt );
-        if( !( offs < F3_INF ) )
-        {
-            V3 c = v_mlf( bg, t.intensity );
-            acc.x += t.T.x * c.x; acc.y += t.T.y * c.y; acc.z += t.T.z * c.z;
-            continue;
-        }
-        shade_hit( sc, q, t.p, t.d, offs, trans, t.depth, t.intensity, t.T, pixel, st, sp, acc, cnt );
+        bool f = go && transparent && intensity >= min_intensity;
+        V3 out_d = rd;
+        if( f ) out_d = fresnel_refraction( rd, trans.exit_nor, trix );
+        push_ray( q, f, ray_pos( rp, rd, offs + 2.0 * F3_EPS ), out_d, T, intensity, depth - 1, pixel );
     }
 }
 
@@ -329,84 +332,103 @@ DEV void wave_add_counters( unsigned long long* global, const Cnt< true >& mine 
 }
 DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
 
-/* level 0: one lane per sample position (lum_machine_s_func, scene.c:976-1011) */
 #ifndef ACN_SHADE_WAVES
 #define ACN_SHADE_WAVES 4
 #endif
 #ifndef ACN_WALK_WAVES
 #define ACN_WALK_WAVES 2
 #endif
-
-/* Kernel parameter convention: every buffer is passed as its own __restrict__ pointer (so that uniform reads of
- * the read-only ones can go through the scalar cache) and the DevScene / Queues views are rebuilt inside. */
+/* Kernel parameter convention: every buffer is passed as its own __restrict__ pointer and the DevScene / Queues views
+ * are rebuilt inside (scene arrays are then read through the constant address space, see acn_device.h). */
 #define ACN_SCENE_PARAMS  DevScene sc_in, const GNode* __restrict__ p_nodes, const GMat* __restrict__ p_mats, const int32_t* __restrict__ p_elems
 #define ACN_SCENE_ARGS( h ) ( h )->dev, ( h )->d_nodes, ( h )->d_mats, ( h )->d_elems
 #define ACN_SCENE_VIEW    DevScene sc = sc_in; sc.nodes = ( NodeP )p_nodes; sc.mats = ( MatP )p_mats; sc.elems = ( ElemP )p_elems; sc.flags = p_counts + QC_FLAGS;
 
-template< bool COUNT >
+#define ACN_WALK_QUEUE_PARAMS DTask* __restrict__ p_tasks, uint32_t* __restrict__ p_idx0, uint32_t* __restrict__ p_idx1, \
+    uint32_t* __restrict__ p_idx2, uint32_t* __restrict__ p_idx3, uint32_t* __restrict__ p_counts, uint32_t task_cap, \
+    RayTask* __restrict__ p_rays_out, uint32_t ray_cap
+#define ACN_WALK_QUEUE_VIEW \
+    Queues q; \
+    q.tasks = p_tasks; q.idx[ 0 ] = p_idx0; q.idx[ 1 ] = p_idx1; q.idx[ 2 ] = p_idx2; q.idx[ 3 ] = p_idx3; \
+    q.children = nullptr; q.counts = p_counts; q.task_cap = task_cap; q.child_cap = 0; \
+    q.hard_shadow = nullptr; q.hard_path = nullptr; q.hard_cap = 0; q.rays_out = p_rays_out; q.ray_cap = ray_cap;
+
+/* One pass of the specular walk: one lane per ray.  PRIMARY: the rays are the camera rays of the sample positions
+ * (lum_machine_s_func, scene.c:976-1011); otherwise they come from the ray queue the previous pass filled.  Each ray
+ * is traced (scene_s_trans_hit) and its hit shaded; what it spawns goes to the next pass / the shading-task queues. */
+template< bool PRIMARY, bool COUNT >
 __global__ __launch_bounds__( 256, ACN_WALK_WAVES )
-void k_walk_primary( ACN_SCENE_PARAMS, DTask* __restrict__ p_tasks, uint32_t* __restrict__ p_idx0, uint32_t* __restrict__ p_idx1,
-                     uint32_t* __restrict__ p_idx2, uint32_t* __restrict__ p_idx3, uint32_t* __restrict__ p_counts, uint32_t task_cap,
-                     const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n,
-                     unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
+void k_trace_rays( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __restrict__ rays_in,
+                   const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n,
+                   unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_SCENE_VIEW
-    Queues q;
-    q.tasks = p_tasks; q.idx[ 0 ] = p_idx0; q.idx[ 1 ] = p_idx1; q.idx[ 2 ] = p_idx2; q.idx[ 3 ] = p_idx3;
-    q.children = nullptr; q.counts = p_counts; q.task_cap = task_cap; q.child_cap = 0;
+    ACN_WALK_QUEUE_VIEW
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     Cnt< COUNT > cnt;
     cnt.clear();
-    if( i < n )
+    bool live = i < n;
+    RayTask t;
+    t.p = mk( 0, 0, 0 ); t.d = mk( 0, 0, 1 ); t.T = mk( 0, 0, 0 ); t.intensity = 0; t.depth = 0; t.pixel = 0;
+    if( live )
     {
-        uint32_t pixel = base + i;
-        double mx, my;
-        if( pos_xy ) { mx = pos_xy[ ( size_t )pixel * 2 ]; my = pos_xy[ ( size_t )pixel * 2 + 1 ]; }
+        if( PRIMARY )
+        {
+            uint32_t pixel = base + i;
+            double mx, my;
+            if( pos_xy ) { mx = pos_xy[ ( size_t )pixel * 2 ]; my = pos_xy[ ( size_t )pixel * 2 + 1 ]; }
+            else
+            {
+                size_t pix = first_pixel + pixel;
+                mx = ( double )( pix % sc.prm.image_width ) + 0.5;
+                my = ( double )( pix / sc.prm.image_width ) + 0.5;
+            }
+            camera_ray( sc, mx, my, &t.p, &t.d );
+            t.T = mk( 1, 1, 1 ); t.intensity = 1.0; t.depth = ( int )sc.prm.trace_depth; t.pixel = pixel;
+        }
         else
         {
-            size_t pix = first_pixel + pixel;
-            mx = ( double )( pix % sc.prm.image_width ) + 0.5;
-            my = ( double )( pix / sc.prm.image_width ) + 0.5;
+            t = rays_in[ i ];
         }
-        RayTask st[ ACN_WALK_STACK ];
-        int sp = 0;
-        V3 acc = mk( 0, 0, 0 );
-        RayTask& t = st[ sp++ ];
-        camera_ray( sc, mx, my, &t.p, &t.d );
-        t.T = mk( 1, 1, 1 ); t.intensity = 1.0; t.depth = ( int )sc.prm.trace_depth;
-        walk_rays( sc, q, pixel, st, sp, acc, &cnt );
-        pixel_add( accum, pixel, acc );
     }
+    V3 acc = mk( 0, 0, 0 );
+    Trans trans;
+    trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
+    double offs = F3_INF;
+    if( live ) offs = scene_trans_hit_dev( sc, t.p, t.d, &trans, &cnt );
+    bool hit = live && offs < F3_INF;
+    if( live && !hit )
+    {
+        V3 c = v_mlf( ld3( sc.prm.background_color ), t.intensity );
+        acc = v_mld( t.T, c );
+    }
+    /* all lanes call shade_hit (its queue appends are wave-wide); lanes without a hit pass depth 0 */
+    shade_hit( sc, q, t.p, t.d, hit ? offs : 0.0, trans, hit ? t.depth : 0, t.intensity, t.T, t.pixel, acc, &cnt );
+    if( live ) pixel_add( accum, t.pixel, acc );
     wave_add_counters( counters, cnt );
 }
 
-/* level >= 1: one lane per path-sample hit */
+/* first pass of a level >= 1: one lane per path-sample hit (the recursive scene_s_lum call of scene.c:610) */
 template< bool COUNT >
 __global__ __launch_bounds__( 256, ACN_WALK_WAVES )
-void k_walk_children( ACN_SCENE_PARAMS, DTask* __restrict__ p_tasks, uint32_t* __restrict__ p_idx0, uint32_t* __restrict__ p_idx1,
-                      uint32_t* __restrict__ p_idx2, uint32_t* __restrict__ p_idx3, uint32_t* __restrict__ p_counts, uint32_t task_cap,
-                      const HitRec* __restrict__ recs, uint32_t n,
-                      unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
+void k_shade_hits( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const HitRec* __restrict__ recs, uint32_t n,
+                   unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_SCENE_VIEW
-    Queues q;
-    q.tasks = p_tasks; q.idx[ 0 ] = p_idx0; q.idx[ 1 ] = p_idx1; q.idx[ 2 ] = p_idx2; q.idx[ 3 ] = p_idx3;
-    q.children = nullptr; q.counts = p_counts; q.task_cap = task_cap; q.child_cap = 0;
+    ACN_WALK_QUEUE_VIEW
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     Cnt< COUNT > cnt;
     cnt.clear();
-    if( i < n )
-    {
-        HitRec r = recs[ i ];
-        RayTask st[ ACN_WALK_STACK ];
-        int sp = 0;
-        V3 acc = mk( 0, 0, 0 );
-        Trans trans;
-        trans.exit_nor = r.exit_nor; trans.exit_obj = r.exit_obj; trans.enter_obj = r.enter_obj;
-        shade_hit( sc, q, r.p, r.d, r.offs, trans, r.depth, r.intensity, r.T, r.pixel, st, sp, acc, &cnt );
-        walk_rays( sc, q, r.pixel, st, sp, acc, &cnt );
-        pixel_add( accum, r.pixel, acc );
-    }
+    bool live = i < n;
+    HitRec r;
+    r.p = mk( 0, 0, 0 ); r.d = mk( 0, 0, 1 ); r.offs = 0; r.exit_nor = mk( 0, 0, 0 ); r.T = mk( 0, 0, 0 ); r.intensity = 0;
+    r.exit_obj = -1; r.enter_obj = -1; r.depth = 0; r.pixel = 0;
+    if( live ) r = recs[ i ];
+    V3 acc = mk( 0, 0, 0 );
+    Trans trans;
+    trans.exit_nor = r.exit_nor; trans.exit_obj = r.exit_obj; trans.enter_obj = r.enter_obj;
+    shade_hit( sc, q, r.p, r.d, r.offs, trans, r.depth, r.intensity, r.T, r.pixel, acc, &cnt );
+    if( live ) pixel_add( accum, r.pixel, acc );
     wave_add_counters( counters, cnt );
 }
 
@@ -427,15 +449,19 @@ template< int LPT > DEV uint64_t lcg_stride( uint64_t x )   /* jump by 2*LPT dra
     return lcg_jump_pow2< 1 >( x );
 }
 
-template< int LPT, bool COUNT >
+/* LEAF_LIGHTS: every light is a plane / sphere / squaroid-free leaf, so the kernel contains no call into the CSG
+ * machine at all (the usual case); otherwise the light hit goes through the generic element test. */
+template< int LPT, bool COUNT, bool LEAF_LIGHTS >
 __global__ __launch_bounds__( 256, ACN_SHADE_WAVES )
 void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t* __restrict__ idx, uint32_t n_tasks,
-              HitRec* __restrict__ p_children, uint32_t child_cap, uint32_t* __restrict__ p_counts,
+              HitRec* __restrict__ p_children, uint32_t child_cap, HardShadow* __restrict__ p_hard_shadow,
+              HardPath* __restrict__ p_hard_path, uint32_t hard_cap, uint32_t* __restrict__ p_counts,
               unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_SCENE_VIEW
     Queues q;
     q.tasks = nullptr; q.children = p_children; q.counts = p_counts; q.task_cap = 0; q.child_cap = child_cap;
+    q.hard_shadow = p_hard_shadow; q.hard_path = p_hard_path; q.hard_cap = hard_cap; q.rays_out = nullptr; q.ray_cap = 0;
     constexpr int G = 64 / LPT;
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPT;
@@ -485,17 +511,35 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 V3 out_d = m_mlv( src_con, v_random_sphere_cap( &r, cyl_hgt ) );
                 double weight = v_mlv( out_d, surface_d );
                 if( weight <= 0 ) continue;
-                int ho;
-                double a = element_hit< false >( sc, light_idx, pos, out_d, nullptr, &ho, -F3_INF, &cnt );
+                double a;
+                if( LEAF_LIGHTS ) a = leaf_element_hit< false >( light_src, light_src->type, pos, out_d, nullptr, &cnt );
+                else { int ho; a = element_hit< false >( sc, light_idx, pos, out_d, nullptr, &ho, -F3_INF, &cnt ); }
                 if( a >= F3_INF ) continue;
                 if( on_b > 0 ) weight = oren_nayar_weight( weight, theta_i, on_a, on_b, out_d, surface_d, ray_projection );
                 cnt.inc( CNT_SHADOW_RAY );
-                if( !root_occluded( sc, sc.matter_root, pos, out_d, a, &cnt ) )
+                V3 hit_pos = ray_pos( pos, out_d, a );
+                double diff_sqr = v_diff_sqr( hit_pos, light_pos );
+                double local_intensity = ( diff_sqr > 0 ) ? ( radiance / diff_sqr ) : F3_MAG;
+                double c = local_intensity * weight * diffuse_intensity;
+                int occ = root_occluded_fast( sc, sc.matter_root, pos, out_d, a, &cnt );
+                if( occ == 0 ) s += c;
+                /* hard shadow rays: compacted into the queue of k_hard_shadow, which adds c itself if unoccluded */
+                uint32_t hs = wave_alloc( &q.counts[ QC_HARD_SHADOW ], occ == 2 );
+                if( occ == 2 )
                 {
-                    V3 hit_pos = ray_pos( pos, out_d, a );
-                    double diff_sqr = v_diff_sqr( hit_pos, light_pos );
-                    double local_intensity = ( diff_sqr > 0 ) ? ( radiance / diff_sqr ) : F3_MAG;
-                    s += local_intensity * weight * diffuse_intensity;
+                    if( hs < q.hard_cap )
+                    {
+                        HardShadow& h = q.hard_shadow[ hs ];
+                        double f = c * ( 2.0 * cyl_hgt / direct_samples );
+                        V3 Tc = ldc( t.Tc );
+                        h.pos = pos; h.d = out_d; h.limit = a;
+                        h.contrib = mk( Tc.x * ( light_mat->color[ 0 ] * f ), Tc.y * ( light_mat->color[ 1 ] * f ), Tc.z * ( light_mat->color[ 2 ] * f ) );
+                        h.pixel = t.pixel; h.pad = 0;
+                    }
+                    else
+                    {
+                        atomicOr( &q.counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+                    }
                 }
             }
             rv = lcg00_jump( rv, 2 * direct_samples );
@@ -525,13 +569,29 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 double a = F3_INF;
                 Trans trans;
                 trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
+                bool hard = false;
                 if( live )
                 {
                     if( on_b > 0 ) weight = oren_nayar_weight( weight, theta_i, on_a, on_b, out_d, surface_d, ray_projection );
-                    a = root_trans_hit( sc, sc.matter_root, pos, out_d, &trans, &cnt );
+                    a = root_trans_hit_fast( sc, sc.matter_root, pos, out_d, &trans, &hard, &cnt );
                 }
-                bool hit = live && a < sc.prm.max_path_length;
-                if( live && !hit ) bsum += weight * diffuse_intensity;
+                bool hit = live && !hard && a < sc.prm.max_path_length;
+                if( live && !hard && !hit ) bsum += weight * diffuse_intensity;
+                /* hard path rays: the transition hit is finished by k_hard_path */
+                uint32_t hp = wave_alloc( &q.counts[ QC_HARD_PATH ], hard );
+                if( hard )
+                {
+                    if( hp < q.hard_cap )
+                    {
+                        HardPath& h = q.hard_path[ hp ];
+                        h.pos = pos; h.d = out_d; h.T = Tchild; h.intensity = weight * diffuse_intensity;
+                        h.depth = t.depth - 10; h.pixel = t.pixel;
+                    }
+                    else
+                    {
+                        atomicOr( &q.counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+                    }
+                }
                 /* compaction of the surviving path rays into the next level's queue */
                 uint32_t cs = wave_alloc( &q.counts[ QC_CHILDREN ], hit );
                 if( hit )
@@ -555,6 +615,69 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
         }
 
         if( sub == 0 ) pixel_add( accum, t.pixel, v_mld( ldc( t.Tc ), lum ) );
+    }
+    wave_add_counters( counters, cnt );
+}
+
+/* the shadow rays k_shade could not decide inline: full occlusion test, one lane per ray */
+template< bool COUNT >
+__global__ __launch_bounds__( 256, ACN_WALK_WAVES )
+void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint32_t n, uint32_t* __restrict__ p_counts,
+                    unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
+{
+    ACN_SCENE_VIEW
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    Cnt< COUNT > cnt;
+    cnt.clear();
+    if( i < n )
+    {
+        HardShadow r = recs[ i ];
+        if( !root_occluded( sc, sc.matter_root, r.pos, r.d, r.limit, &cnt ) ) pixel_add( accum, r.pixel, r.contrib );
+    }
+    wave_add_counters( counters, cnt );
+}
+
+/* the path rays k_shade could not finish inline: full transition hit; hits join the next level's HitRec queue */
+template< bool COUNT >
+__global__ __launch_bounds__( 256, ACN_WALK_WAVES )
+void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t n, HitRec* __restrict__ p_children, uint32_t child_cap,
+                  uint32_t* __restrict__ p_counts, unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
+{
+    ACN_SCENE_VIEW
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    Cnt< COUNT > cnt;
+    cnt.clear();
+    bool hit = false;
+    HardPath r;
+    Trans trans;
+    trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
+    double a = F3_INF;
+    if( i < n )
+    {
+        r = recs[ i ];
+        a = root_trans_hit( sc, sc.matter_root, r.pos, r.d, &trans, &cnt );
+        hit = a < sc.prm.max_path_length;
+        if( !hit )
+        {
+            V3 c = v_mlf( ld3( sc.prm.background_color ), r.intensity );
+            pixel_add( accum, r.pixel, v_mld( r.T, c ) );
+        }
+    }
+    uint32_t cs = wave_alloc( &p_counts[ QC_CHILDREN ], hit );
+    if( hit )
+    {
+        if( cs < child_cap )
+        {
+            HitRec& c = p_children[ cs ];
+            c.p = r.pos; c.d = r.d; c.offs = a; c.exit_nor = trans.exit_nor; c.T = r.T;
+            c.intensity = r.intensity;
+            c.exit_obj = trans.exit_obj; c.enter_obj = trans.enter_obj;
+            c.depth = r.depth; c.pixel = r.pixel;
+        }
+        else
+        {
+            atomicOr( &p_counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+        }
     }
     wave_add_counters( counters, cnt );
 }

@@ -33,12 +33,16 @@ struct acn_scene_handle
     int max_csg_depth = 0;
     /* workspace of the wavefront pipeline */
     Queues q{};
+    RayTask* rays[ 2 ] = { nullptr, nullptr };  /* ping-pong ray queues of the specular walk */
     uint32_t* h_counts = nullptr;              /* pinned */
     unsigned long long* d_accum = nullptr;  size_t accum_cap = 0;
     unsigned long long* d_counters = nullptr;
     std::vector< StageEvents > events;  size_t events_used = 0;
+    bool leaf_lights = true;                   /* every light element is a plane / sphere */
     bool count_work = false;                   /* ACN_OPT_COUNT_WORK of the current call */
-    uint64_t launches[ 3 ] = { 0, 0, 0 };
+    uint64_t launches[ 4 ] = { 0, 0, 0, 0 };   /* walk, shade, finalize, hard-ray kernels */
+    uint64_t hard_rays = 0, walk_passes = 0;
+    size_t good_chunk = 0;
     uint64_t chunks = 0, retries = 0, levels = 0;
     uint64_t peak_tasks = 0, peak_children = 0;
 };
@@ -334,6 +338,14 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     h->dev.n_nodes = scene->n_nodes;
     h->dev.n_elems = scene->n_elems;
     h->dev.prm = scene->params;
+    {
+        const acn_node& lr = scene->nodes[ scene->light_root ];
+        for( int k = 0; k < lr.child1; k++ )
+        {
+            int t = scene->nodes[ scene->elems[ lr.child0 + k ] ].type;
+            if( t != ACN_PLANE && t != ACN_SPHERE ) h->leaf_lights = false;
+        }
+    }
     h->dev.flags = h->q.counts + QC_FLAGS;
     HIP_TRY_H( hipMemset( h->q.counts, 0, sizeof( uint32_t ) * QC_N ) );
     /* camera basis on the device so that it shares the device's arithmetic */
@@ -357,6 +369,10 @@ static void free_workspace( acn_scene_handle* h )
     if( h->q.tasks ) hipFree( h->q.tasks );
     for( int k = 0; k < ACN_NCLASS; k++ ) if( h->q.idx[ k ] ) hipFree( h->q.idx[ k ] );
     if( h->q.children ) hipFree( h->q.children );
+    if( h->q.hard_shadow ) hipFree( h->q.hard_shadow );
+    if( h->q.hard_path ) hipFree( h->q.hard_path );
+    for( int k = 0; k < 2; k++ ) { if( h->rays[ k ] ) hipFree( h->rays[ k ] ); h->rays[ k ] = nullptr; }
+    h->q.hard_shadow = nullptr; h->q.hard_path = nullptr; h->q.hard_cap = 0;
     h->q.tasks = nullptr; h->q.children = nullptr; h->q.task_cap = h->q.child_cap = 0;
     for( int k = 0; k < ACN_NCLASS; k++ ) h->q.idx[ k ] = nullptr;
 }
@@ -381,12 +397,12 @@ extern "C" void acn_scene_free( acn_scene_handle* h )
 }
 
 /* queue capacities for a call over n positions: enough for every path sample of the largest chunk to hit, bounded
- * by ACN_WORKSPACE_MB (default 20480) */
+ * by ACN_WORKSPACE_MB (default 65536) */
 static int ensure_workspace( acn_scene_handle* h, size_t n )
 {
-    size_t budget_mb = 20480;
+    size_t budget_mb = 65536;
     if( const char* e = getenv( "ACN_WORKSPACE_MB" ) ) budget_mb = ( size_t )atoll( e );
-    size_t per_rec = sizeof( HitRec ) + sizeof( DTask ) + ACN_NCLASS * sizeof( uint32_t );
+    size_t per_rec = sizeof( HitRec ) + sizeof( DTask ) + ACN_NCLASS * sizeof( uint32_t ) + sizeof( HardShadow ) + sizeof( HardPath ) + 2 * sizeof( RayTask );
     size_t max_recs = budget_mb * 1024 * 1024 / per_rec;
     size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
     size_t want = n * ( s + 2 ) + 65536;
@@ -398,8 +414,13 @@ static int ensure_workspace( acn_scene_handle* h, size_t n )
     HIP_TRY( hipMalloc( &h->q.children, sizeof( HitRec ) * want ) );
     HIP_TRY( hipMalloc( &h->q.tasks, sizeof( DTask ) * want ) );
     for( int k = 0; k < ACN_NCLASS; k++ ) HIP_TRY( hipMalloc( &h->q.idx[ k ], sizeof( uint32_t ) * want ) );
+    HIP_TRY( hipMalloc( &h->q.hard_shadow, sizeof( HardShadow ) * want ) );
+    HIP_TRY( hipMalloc( &h->q.hard_path, sizeof( HardPath ) * want ) );
+    for( int k = 0; k < 2; k++ ) HIP_TRY( hipMalloc( &h->rays[ k ], sizeof( RayTask ) * want ) );
+    h->q.ray_cap = ( uint32_t )want;
     h->q.child_cap = ( uint32_t )want;
     h->q.task_cap = ( uint32_t )want;
+    h->q.hard_cap = ( uint32_t )want;
     return ACN_OK;
 }
 
@@ -442,42 +463,80 @@ static int launch_shade( acn_scene_handle* h, int cls, uint32_t n_tasks, hipStre
     if( blocks > 256 * 32 ) blocks = 256 * 32;
     int st = stage_begin( h, 1, stream );
     if( st != ACN_OK ) return st;
-    if( h->count_work )
-        hipLaunchKernelGGL( ( k_shade< LPT, true > ), dim3( ( unsigned )blocks ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                            ( const DTask* )h->q.tasks, ( const uint32_t* )h->q.idx[ cls ], n_tasks, h->q.children, h->q.child_cap,
-                            h->q.counts, h->d_accum, h->d_counters );
-    else
-        hipLaunchKernelGGL( ( k_shade< LPT, false > ), dim3( ( unsigned )blocks ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                            ( const DTask* )h->q.tasks, ( const uint32_t* )h->q.idx[ cls ], n_tasks, h->q.children, h->q.child_cap,
-                            h->q.counts, h->d_accum, h->d_counters );
+#define ACN_LAUNCH_SHADE( C, L ) hipLaunchKernelGGL( ( k_shade< LPT, C, L > ), dim3( ( unsigned )blocks ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ), \
+                            ( const DTask* )h->q.tasks, ( const uint32_t* )h->q.idx[ cls ], n_tasks, h->q.children, h->q.child_cap, \
+                            h->q.hard_shadow, h->q.hard_path, h->q.hard_cap, h->q.counts, h->d_accum, h->d_counters )
+    if( h->count_work ) { if( h->leaf_lights ) ACN_LAUNCH_SHADE( true, true ); else ACN_LAUNCH_SHADE( true, false ); }
+    else                { if( h->leaf_lights ) ACN_LAUNCH_SHADE( false, true ); else ACN_LAUNCH_SHADE( false, false ); }
+#undef ACN_LAUNCH_SHADE
     HIP_TRY( hipGetLastError() );
     return stage_end( h, stream );
 }
 
-/* One chunk of positions [ base, base + cnt ): walk -> ( shade -> walk )* .  Returns 1 if a queue overflowed. */
+#define ACN_WALK_QUEUE_ARGS( h, out ) ( h )->q.tasks, ( h )->q.idx[ 0 ], ( h )->q.idx[ 1 ], ( h )->q.idx[ 2 ], ( h )->q.idx[ 3 ], ( h )->q.counts, \
+    ( h )->q.task_cap, ( h )->rays[ out ], ( h )->q.ray_cap
+
+static int check_flags( acn_scene_handle* h, int* overflow )
+{
+    if( h->h_counts[ QC_FLAGS ] & ACN_FLAG_STACK_OVERFLOW ) return fail( ACN_ERR_UNSUPPORTED, "device CSG / compound stack overflow" );
+    if( h->h_counts[ QC_FLAGS ] ) *overflow = 1;
+    return ACN_OK;
+}
+
+/* the specular walk of one level: passes of k_trace_rays until no ray is left. `n_in` rays wait in rays[ *cur ]. */
+static int walk_passes( acn_scene_handle* h, uint32_t n_in, int* cur, hipStream_t stream, int* overflow )
+{
+    int st;
+    for( int pass = 0; n_in > 0; pass++ )
+    {
+        if( pass > 4096 ) return fail( ACN_ERR_DEVICE, "specular walk does not terminate" );
+        int in = *cur, out = 1 - in;
+        HIP_TRY( hipMemsetAsync( h->q.counts + QC_RAYS, 0, sizeof( uint32_t ), stream ) );
+        if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
+        if( h->count_work )
+            hipLaunchKernelGGL( ( k_trace_rays< false, true > ), dim3( ( n_in + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                                ACN_WALK_QUEUE_ARGS( h, out ), ( const RayTask* )h->rays[ in ], ( const double* )nullptr, ( size_t )0, 0u, n_in,
+                                h->d_accum, h->d_counters );
+        else
+            hipLaunchKernelGGL( ( k_trace_rays< false, false > ), dim3( ( n_in + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                                ACN_WALK_QUEUE_ARGS( h, out ), ( const RayTask* )h->rays[ in ], ( const double* )nullptr, ( size_t )0, 0u, n_in,
+                                h->d_accum, h->d_counters );
+        HIP_TRY( hipGetLastError() );
+        if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
+        if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
+        if( ( st = check_flags( h, overflow ) ) != ACN_OK || *overflow ) return st;
+        h->walk_passes++;
+        n_in = h->h_counts[ QC_RAYS ];
+        *cur = out;
+    }
+    return ACN_OK;
+}
+
+/* One chunk of positions [ base, base + cnt ): per path level  walk passes -> k_shade -> hard-ray kernels. */
 static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t first_pixel, uint32_t base, uint32_t cnt,
                          hipStream_t stream, int* overflow )
 {
     *overflow = 0;
     int st;
+    int cur = 0;
     HIP_TRY( hipMemsetAsync( h->q.counts, 0, sizeof( uint32_t ) * QC_N, stream ) );
+    /* level 0, pass 0: the camera rays */
     if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
     if( h->count_work )
-        hipLaunchKernelGGL( k_walk_primary< true >, dim3( ( cnt + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                            h->q.tasks, h->q.idx[ 0 ], h->q.idx[ 1 ], h->q.idx[ 2 ], h->q.idx[ 3 ], h->q.counts, h->q.task_cap,
-                            d_pos_xy, first_pixel, base, cnt, h->d_accum, h->d_counters );
+        hipLaunchKernelGGL( ( k_trace_rays< true, true > ), dim3( ( cnt + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                            ACN_WALK_QUEUE_ARGS( h, cur ), ( const RayTask* )nullptr, d_pos_xy, first_pixel, base, cnt, h->d_accum, h->d_counters );
     else
-        hipLaunchKernelGGL( k_walk_primary< false >, dim3( ( cnt + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                            h->q.tasks, h->q.idx[ 0 ], h->q.idx[ 1 ], h->q.idx[ 2 ], h->q.idx[ 3 ], h->q.counts, h->q.task_cap,
-                            d_pos_xy, first_pixel, base, cnt, h->d_accum, h->d_counters );
+        hipLaunchKernelGGL( ( k_trace_rays< true, false > ), dim3( ( cnt + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                            ACN_WALK_QUEUE_ARGS( h, cur ), ( const RayTask* )nullptr, d_pos_xy, first_pixel, base, cnt, h->d_accum, h->d_counters );
     HIP_TRY( hipGetLastError() );
     if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
+    if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
+    if( ( st = check_flags( h, overflow ) ) != ACN_OK || *overflow ) return st;
+    if( ( st = walk_passes( h, h->h_counts[ QC_RAYS ], &cur, stream, overflow ) ) != ACN_OK || *overflow ) return st;
 
     for( int level = 0; level < ACN_MAX_PATH_LEVELS + 1; level++ )
     {
-        if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
-        if( h->h_counts[ QC_FLAGS ] & ACN_FLAG_STACK_OVERFLOW ) return fail( ACN_ERR_UNSUPPORTED, "device ray / CSG stack overflow" );
-        if( h->h_counts[ QC_FLAGS ] ) { *overflow = 1; return ACN_OK; }
+        /* h_counts holds the counts after the last walk pass of this level */
         uint32_t n_cls[ ACN_NCLASS ];
         uint32_t total = 0;
         for( int k = 0; k < ACN_NCLASS; k++ ) { n_cls[ k ] = h->h_counts[ QC_CLASS0 + k ]; total += n_cls[ k ]; }
@@ -485,29 +544,62 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
         if( total == 0 ) break;
         h->levels++;
         HIP_TRY( hipMemsetAsync( h->q.counts + QC_CHILDREN, 0, sizeof( uint32_t ), stream ) );
+        HIP_TRY( hipMemsetAsync( h->q.counts + QC_HARD_SHADOW, 0, 2 * sizeof( uint32_t ), stream ) );
         if( ( st = launch_shade< 64 >( h, 0, n_cls[ 0 ], stream ) ) != ACN_OK ) return st;
         if( ( st = launch_shade< 16 >( h, 1, n_cls[ 1 ], stream ) ) != ACN_OK ) return st;
         if( ( st = launch_shade< 4 >( h, 2, n_cls[ 2 ], stream ) ) != ACN_OK ) return st;
         if( ( st = launch_shade< 1 >( h, 3, n_cls[ 3 ], stream ) ) != ACN_OK ) return st;
         if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
-        if( h->h_counts[ QC_FLAGS ] & ACN_FLAG_STACK_OVERFLOW ) return fail( ACN_ERR_UNSUPPORTED, "device ray / CSG stack overflow" );
-        if( h->h_counts[ QC_FLAGS ] ) { *overflow = 1; return ACN_OK; }
+        if( ( st = check_flags( h, overflow ) ) != ACN_OK || *overflow ) return st;
+        /* the rays k_shade deferred: full traversal, one lane per ray */
+        {
+            uint32_t n_hs = h->h_counts[ QC_HARD_SHADOW ], n_hp = h->h_counts[ QC_HARD_PATH ];
+            h->hard_rays += ( uint64_t )n_hs + n_hp;
+            if( n_hs )
+            {
+                if( ( st = stage_begin( h, 3, stream ) ) != ACN_OK ) return st;
+                if( h->count_work )
+                    hipLaunchKernelGGL( k_hard_shadow< true >, dim3( ( n_hs + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                                        ( const HardShadow* )h->q.hard_shadow, n_hs, h->q.counts, h->d_accum, h->d_counters );
+                else
+                    hipLaunchKernelGGL( k_hard_shadow< false >, dim3( ( n_hs + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                                        ( const HardShadow* )h->q.hard_shadow, n_hs, h->q.counts, h->d_accum, h->d_counters );
+                HIP_TRY( hipGetLastError() );
+                if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
+            }
+            if( n_hp )
+            {
+                if( ( st = stage_begin( h, 3, stream ) ) != ACN_OK ) return st;
+                if( h->count_work )
+                    hipLaunchKernelGGL( k_hard_path< true >, dim3( ( n_hp + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                                        ( const HardPath* )h->q.hard_path, n_hp, h->q.children, h->q.child_cap, h->q.counts, h->d_accum, h->d_counters );
+                else
+                    hipLaunchKernelGGL( k_hard_path< false >, dim3( ( n_hp + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                                        ( const HardPath* )h->q.hard_path, n_hp, h->q.children, h->q.child_cap, h->q.counts, h->d_accum, h->d_counters );
+                HIP_TRY( hipGetLastError() );
+                if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
+                if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
+                if( ( st = check_flags( h, overflow ) ) != ACN_OK || *overflow ) return st;
+            }
+        }
         uint32_t n_children = h->h_counts[ QC_CHILDREN ];
         if( n_children > h->peak_children ) h->peak_children = n_children;
         if( n_children == 0 ) break;
-        /* next level: the task queues are consumed, the child queue feeds the walk */
+        /* next level: the task queues are consumed; the path-sample hits are shaded, then their specular rays walked */
         HIP_TRY( hipMemsetAsync( h->q.counts, 0, sizeof( uint32_t ) * QC_CHILDREN, stream ) );
+        HIP_TRY( hipMemsetAsync( h->q.counts + QC_RAYS, 0, sizeof( uint32_t ), stream ) );
         if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
         if( h->count_work )
-            hipLaunchKernelGGL( k_walk_children< true >, dim3( ( n_children + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                                h->q.tasks, h->q.idx[ 0 ], h->q.idx[ 1 ], h->q.idx[ 2 ], h->q.idx[ 3 ], h->q.counts, h->q.task_cap,
-                                ( const HitRec* )h->q.children, n_children, h->d_accum, h->d_counters );
+            hipLaunchKernelGGL( k_shade_hits< true >, dim3( ( n_children + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                                ACN_WALK_QUEUE_ARGS( h, cur ), ( const HitRec* )h->q.children, n_children, h->d_accum, h->d_counters );
         else
-            hipLaunchKernelGGL( k_walk_children< false >, dim3( ( n_children + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                                h->q.tasks, h->q.idx[ 0 ], h->q.idx[ 1 ], h->q.idx[ 2 ], h->q.idx[ 3 ], h->q.counts, h->q.task_cap,
-                                ( const HitRec* )h->q.children, n_children, h->d_accum, h->d_counters );
+            hipLaunchKernelGGL( k_shade_hits< false >, dim3( ( n_children + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
+                                ACN_WALK_QUEUE_ARGS( h, cur ), ( const HitRec* )h->q.children, n_children, h->d_accum, h->d_counters );
         HIP_TRY( hipGetLastError() );
         if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
+        if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
+        if( ( st = check_flags( h, overflow ) ) != ACN_OK || *overflow ) return st;
+        if( ( st = walk_passes( h, h->h_counts[ QC_RAYS ], &cur, stream, overflow ) ) != ACN_OK || *overflow ) return st;
     }
     return ACN_OK;
 }
@@ -530,7 +622,8 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
         h->accum_cap = n;
     }
     h->events_used = 0;
-    h->launches[ 0 ] = h->launches[ 1 ] = h->launches[ 2 ] = 0;
+    h->launches[ 0 ] = h->launches[ 1 ] = h->launches[ 2 ] = h->launches[ 3 ] = 0;
+    h->hard_rays = 0; h->walk_passes = 0;
     h->chunks = h->retries = h->levels = 0;
     h->peak_tasks = h->peak_children = 0;
     HIP_TRY( hipMemsetAsync( h->d_counters, 0, sizeof( unsigned long long ) * CNT_N, stream ) );
@@ -538,8 +631,10 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     HIP_TRY( hipMemsetAsync( h->d_accum, 0, sizeof( unsigned long long ) * 3 * n, stream ) );
 
     /* chunk so that every path sample of a chunk may survive into the next level's queue */
+    /* optimistic start (a quarter of the path samples survive); an overflow halves the chunk and the size that worked
+     * is remembered for the next call on this handle */
     size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
-    size_t chunk = h->q.child_cap / ( s + 2 );
+    size_t chunk = h->good_chunk ? h->good_chunk : h->q.child_cap / ( s / 4 + 2 );
     if( const char* e = getenv( "ACN_CHUNK" ) ) chunk = ( size_t )atoll( e );
     if( chunk < 256 ) chunk = 256;
     size_t base = 0;
@@ -555,6 +650,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
             if( cnt <= 64 ) return fail( ACN_ERR_DEVICE, "work queues overflow even for 64 positions: raise ACN_WORKSPACE_MB" );
             h->retries++;
             chunk = cnt / 2;
+            h->good_chunk = chunk;
             HIP_TRY( hipMemsetAsync( h->d_accum + 3 * base, 0, sizeof( unsigned long long ) * 3 * cnt, stream ) );
             continue;
         }
@@ -647,7 +743,7 @@ extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
     if( !h || !out || n < 0 || n > 16 || !h->timed ) return fail( ACN_ERR_ARG, "no timed launch" );
     HIP_TRY( hipSetDevice( h->device ) );
     HIP_TRY( hipEventSynchronize( h->ev1 ) );
-    double ms[ 3 ] = { 0, 0, 0 };
+    double ms[ 4 ] = { 0, 0, 0, 0 };
     for( size_t i = 0; i < h->events_used; i++ )
     {
         float t = 0;
@@ -658,7 +754,7 @@ extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
     HIP_TRY( hipEventElapsedTime( &total, h->ev0, h->ev1 ) );
     double v[ 16 ] = { ms[ 0 ], ms[ 1 ], ms[ 2 ], total, ( double )h->launches[ 0 ], ( double )h->launches[ 1 ], ( double )h->launches[ 2 ],
                        ( double )h->chunks, ( double )h->retries, ( double )h->levels, ( double )h->peak_tasks, ( double )h->peak_children,
-                       ( double )h->q.child_cap, 0, 0, 0 };
+                       ( double )h->q.child_cap, ms[ 3 ], ( double )h->launches[ 3 ], ( double )h->hard_rays };
     for( int k = 0; k < n; k++ ) out[ k ] = v[ k ];
     return ACN_OK;
 }
