@@ -5,7 +5,7 @@ ROOT     := $(dir $(abspath $(lastword $(MAKEFILE_LIST))))
 LIBDIR   := actinon_amd/lib
 CFLAGS   := -O2 -fPIC -std=gnu11 -Wall -Wno-unused-function -ffp-contract=off -Iinclude
 SHADE_WAVES ?= 4
-WALK_WAVES  ?= 2
+WALK_WAVES  ?= 4
 EXTRA_DEFS ?=
 HIPFLAGS := $(EXTRA_DEFS) -DACN_SHADE_WAVES=$(SHADE_WAVES) -DACN_WALK_WAVES=$(WALK_WAVES) -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Iinclude -Iactinon_amd/csrc -std=c++17 -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
 

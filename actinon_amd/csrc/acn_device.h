@@ -24,6 +24,23 @@
 
 #define DEV __device__ __forceinline__
 #define DEVN __device__ __noinline__
+/* inlining policy of the two CSG machines (measured on MI355X) */
+#ifndef ACN_SIDE_INLINE
+#define ACN_SIDE_INLINE 1
+#endif
+#ifndef ACN_HIT_INLINE
+#define ACN_HIT_INLINE 1
+#endif
+#if ACN_SIDE_INLINE
+#define DEV_SIDE __device__ __forceinline__
+#else
+#define DEV_SIDE __device__ __noinline__
+#endif
+#if ACN_HIT_INLINE
+#define DEV_HIT __device__ __forceinline__
+#else
+#define DEV_HIT __device__ __noinline__
+#endif
 
 #define F3_INF ( __builtin_huge_val() )
 #define F3_MAG 1E+30
@@ -499,7 +516,7 @@ DEV int distance_side( NodeP o, V3 pos )   /* objects.c:961-966 */
 struct SideFrame { int node; int pc; V3 pos; };
 
 template< class CT >
-DEVN int obj_side_dev( SceneRef sc, int root, V3 pos, CT* cnt )
+DEV_SIDE int obj_side_dev( SceneRef sc, int root, V3 pos, CT* cnt )
 {
     SideFrame st[ ACN_CSG_MAX_DEPTH ];
     SideFrame cur;
@@ -603,7 +620,7 @@ DEV V3 roughness_normal( NodeP hdr, V3 n, V3 hit_pos )   /* objects.c:267-282 */
 }
 
 template< class CT >
-DEVN double obj_ray_hit_dev( SceneRef sc, int root, V3 rp, V3 rd, bool want_nor, V3* out_nor, CT* cnt )
+DEV_HIT double obj_ray_hit_dev( SceneRef sc, int root, V3 rp, V3 rd, bool want_nor, V3* out_nor, CT* cnt )
 {
     HitFrame st[ ACN_CSG_MAX_DEPTH ];
     HitFrame cur;
@@ -813,6 +830,29 @@ DEVN double compound_ray_hit_dev( SceneRef sc, int cmp, V3 rp, V3 rd, bool want_
     return min_a;
 }
 
+/* Conservative pruning before a ray is handed to the CSG machine: surely_outside( n ) == true guarantees that the
+ * whole ray lies outside n's bounding envelopes, in which case the reference returns f3_inf for n AND obj_side( n )
+ * is +1 at every point of the ray:
+ *   - n has an envelope and the ray misses it (objects.c:264, :368);
+ *   - pair_outside: both children surely outside -> a1 = a2 = f3_inf -> f3_inf (objects.c:1224), side 1+1 == 2;
+ *   - pair_inside: one child surely outside -> it returns f3_inf and classifies every point of the ray as outside, so
+ *     neither the direct candidates nor the alternating walk can accept a hit (objects.c:1057-1092), side != -2.
+ * Complements and scale wrappers are never pruned.  Expanded D levels deep. */
+template< int D >
+DEV bool surely_outside( const DevScene& sc, int node, V3 rp, V3 rd )
+{
+    NodeP n = &sc.nodes[ node ];
+    if( node_has_env( n ) && !env_ray_hits( n, rp, rd ) ) return true;
+    if constexpr( D > 0 )
+    {
+        int type = n->type;
+        if( type == ACN_PAIR_OUTSIDE ) return surely_outside< D - 1 >( sc, n->child0, rp, rd ) && surely_outside< D - 1 >( sc, n->child1, rp, rd );
+        if( type == ACN_PAIR_INSIDE )  return surely_outside< D - 1 >( sc, n->child0, rp, rd ) || surely_outside< D - 1 >( sc, n->child1, rp, rd );
+    }
+    return false;
+}
+#define ACN_PRUNE_DEPTH 3
+
 /* Hit test of ROOT element `e` (an index that is the same in every active lane of the wave, so the node is read
  * through the scalar cache into SGPRs and the type dispatch is a scalar branch): obj_ray_hit (objects.c:261-284)
  * for objects -- plane / sphere / squaroid inline, CSG and SDF objects through the hit machine -- and
@@ -826,7 +866,11 @@ DEV double element_hit( const DevScene& sc, int e, V3 rp, V3 rd, V3* nor, int* h
     *hit_obj = e;
     bool env = node_has_env( n );
     if( env && !env_ray_hits( n, rp, rd ) ) { cnt->inc( CNT_OBJ_HIT ); return F3_INF; }
-    if( type > ACN_SQUAROID ) return obj_ray_hit_dev( sref( sc ), e, rp, rd, NOR, nor, cnt );   /* the machine redoes the envelope test */
+    if( type > ACN_SQUAROID )
+    {
+        if( type != ACN_DISTANCE && surely_outside< ACN_PRUNE_DEPTH >( sc, e, rp, rd ) ) { cnt->inc( CNT_OBJ_HIT ); return F3_INF; }
+        return obj_ray_hit_dev( sref( sc ), e, rp, rd, NOR, nor, cnt );   /* the machine redoes the envelope test */
+    }
     cnt->inc( CNT_OBJ_HIT );
     double a;
     if( type == ACN_PLANE )       a = plane_ray_hit( ld3( n->pos ), ld3( n->rax + 6 ), rp, rd, NOR, nor );
@@ -933,7 +977,8 @@ DEV int root_occluded_fast( const DevScene& sc, int cmp, V3 rp, V3 rd, double li
             double a = leaf_element_hit< false >( n, type, rp, rd, nullptr, cnt );
             if( a <= limit ) return 1;
         }
-        else if( !node_has_env( n ) || env_ray_hits( n, rp, rd ) )
+        else if( type == ACN_COMPOUND || type == ACN_DISTANCE ? ( !node_has_env( n ) || env_ray_hits( n, rp, rd ) )
+                                                              : !surely_outside< ACN_PRUNE_DEPTH >( sc, element, rp, rd ) )
         {
             hard = true;
         }
@@ -958,7 +1003,8 @@ DEV double root_trans_hit_fast( const DevScene& sc, int cmp, V3 rp, V3 rd, Trans
         int type = n->type;
         if( !is_fast_type( type ) )
         {
-            if( !node_has_env( n ) || env_ray_hits( n, rp, rd ) ) h = true;
+            if( type == ACN_COMPOUND || type == ACN_DISTANCE ? ( !node_has_env( n ) || env_ray_hits( n, rp, rd ) )
+                                                             : !surely_outside< ACN_PRUNE_DEPTH >( sc, element, rp, rd ) ) h = true;
             continue;
         }
         V3 nor = mk( 0, 0, 0 );

@@ -336,7 +336,7 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
 #define ACN_SHADE_WAVES 4
 #endif
 #ifndef ACN_WALK_WAVES
-#define ACN_WALK_WAVES 2
+#define ACN_WALK_WAVES 4
 #endif
 /* Kernel parameter convention: every buffer is passed as its own __restrict__ pointer and the DevScene / Queues views
  * are rebuilt inside (scene arrays are then read through the constant address space, see acn_device.h). */
