@@ -112,11 +112,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    # ACN_BENCH_SINGLE_DEVICE=1: rehearsal of the N > 1 code path on a 1-GPU box (every rank on cuda:0, gloo
+    # all-reduce through host memory). Never used for reported numbers.
+    rehearsal = os.environ.get("ACN_BENCH_SINGLE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     builder, ov = WORKLOADS[args.workload]
     scene = A.Scene.build(builder, **ov)
@@ -142,7 +150,12 @@ def main():
             handle.render_positions_dev(pos.data_ptr(), pos.shape[0], part.data_ptr(), linear=True, stream=stream)
             frame.zero_()
             frame.index_copy_(0, idx, part)
-            dist.all_reduce(frame, op=dist.ReduceOp.SUM)
+            if rehearsal:
+                host = frame.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                frame.copy_(host)
+            else:
+                dist.all_reduce(frame, op=dist.ReduceOp.SUM)
             if rank == 0:
                 handle.resolve_dev(frame.data_ptr(), n_pix, None, rgb8.data_ptr(), stream=stream)
                 host_img.copy_(rgb8, non_blocking=True)
@@ -169,7 +182,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -207,7 +220,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" + (" (single-device rehearsal of the multi-rank path, not a measurement)" if rehearsal else ""),
             "config": {"workload": f"{builder} {W}x{H} path_samples={S} direct_samples={int(flat.params.direct_samples)} "
                                    f"trace_depth={int(flat.params.trace_depth)} (BASELINE.json configs[1] scene+sampling"
                                    f"{' at the metric resolution 1920x1080' if args.workload == 'wine_glass_1080p' else ''})"
