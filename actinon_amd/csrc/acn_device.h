@@ -373,9 +373,18 @@ DEV M3 node_rax( NodeP n )
     m.x = ld3( n->rax ); m.y = ld3( n->rax + 3 ); m.z = ld3( n->rax + 6 );
     return m;
 }
-DEV bool env_ray_hits( NodeP n, V3 rp, V3 rd )   /* objects.c:90-93 */
+/* envelope_s_ray_hits (objects.c:90-93) = sphere_ray_hit( ... ) < f3_inf.  Only the predicate is needed: by
+ * gmath.h:64-83 the offset is finite exactly when s*s >= q and ( s < 0 or q < 0 ) -- the square root of the
+ * non-negative discriminant is finite for finite inputs -- so the sqrt is not evaluated. */
+DEV bool env_ray_hits( NodeP n, V3 rp, V3 rd )
 {
-    return sphere_ray_hit( ld3( n->env_pos ), n->env_radius, rp, rd, false, nullptr ) < F3_INF;
+    V3 p = v_sub( rp, ld3( n->env_pos ) );
+    double r = n->env_radius;
+    double s = v_mlv( p, rd );
+    double q = v_sqr( p ) - ( r * r );
+    double s2 = s * s;
+    if( s2 < q ) return false;
+    return ( s < 0 && q > 0 ) || ( s < 0 || q < 0 );
 }
 DEV int env_side( NodeP n, V3 pos ) { return sphere_observer_side( ld3( n->env_pos ), n->env_radius, pos ); }
 
