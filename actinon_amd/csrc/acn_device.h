@@ -98,10 +98,15 @@ typedef const GMat    ACN_CONST* MatP;
 typedef const int32_t ACN_CONST* ElemP;
 typedef const double  ACN_CONST* CDblP;
 
-/* device-resident scene */
-struct DevScene
+/* node array staged in LDS (per workgroup) for the kernels whose node accesses are per-lane */
+#define ACN_LDS __attribute__( ( address_space( 3 ) ) )
+typedef const GNode ACN_LDS* LdsNodeP;
+
+/* device-resident scene, parameterised by where the node array is read from */
+template< class NP >
+struct DevSceneT
 {
-    NodeP nodes;
+    NP nodes;
     MatP  mats;
     ElemP elems;
     int32_t light_root, matter_root;
@@ -112,6 +117,18 @@ struct DevScene
     double unit_f;
     uint32_t* flags;     /* device word for ACN_FLAG_* error bits */
 };
+typedef DevSceneT< NodeP > DevScene;
+
+/* the same scene with its node array read from another address space */
+template< class NP2 >
+__device__ __forceinline__ DevSceneT< NP2 > scene_rebind( const DevScene& sc, NP2 nodes )
+{
+    DevSceneT< NP2 > r;
+    r.nodes = nodes; r.mats = sc.mats; r.elems = sc.elems;
+    r.light_root = sc.light_root; r.matter_root = sc.matter_root; r.n_nodes = sc.n_nodes; r.n_elems = sc.n_elems;
+    r.prm = sc.prm; r.camera_rotation = sc.camera_rotation; r.unit_f = sc.unit_f; r.flags = sc.flags;
+    return r;
+}
 
 enum
 {
@@ -137,16 +154,15 @@ template<> struct Cnt< false >
 
 /* the two read-only scene arrays, passed BY VALUE into the non-inlined machines (global address space, so the
  * scene struct is never forced into scratch) */
-struct SceneRef { NodeP nodes; ElemP elems; uint32_t* flags; };
+template< class NP > struct SceneRefT { NP nodes; ElemP elems; uint32_t* flags; };
 #define ACN_FLAG_TASK_OVERFLOW  1u
 #define ACN_FLAG_CHILD_OVERFLOW 2u
 #define ACN_FLAG_STACK_OVERFLOW 4u   /* CSG / compound / ray stack exhausted: the result would be wrong, the call fails */
-__device__ __forceinline__ SceneRef sref( const DevScene& sc ) { SceneRef r; r.nodes = sc.nodes; r.elems = sc.elems; r.flags = sc.flags; return r; }
+template< class NP > __device__ __forceinline__ SceneRefT< NP > sref( const DevSceneT< NP >& sc ) { SceneRefT< NP > r; r.nodes = sc.nodes; r.elems = sc.elems; r.flags = sc.flags; return r; }
 
 /* ---- vectors.h ---- */
 DEV V3 mk( double x, double y, double z ) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
-DEV V3 ld3( const double* p ) { return mk( p[ 0 ], p[ 1 ], p[ 2 ] ); }
-DEV V3 ld3( CDblP p ) { return mk( p[ 0 ], p[ 1 ], p[ 2 ] ); }
+template< class P > DEV V3 ld3( P p ) { return mk( p[ 0 ], p[ 1 ], p[ 2 ] ); }
 DEV V3 ldc( const V3 ACN_CONST& v ) { return mk( v.x, v.y, v.z ); }
 DEV V3 v_neg( V3 o ) { return mk( -o.x, -o.y, -o.z ); }
 DEV double v_sqr( V3 o ) { return ( o.x * o.x ) + ( o.y * o.y ) + ( o.z * o.z ); }
@@ -366,8 +382,8 @@ DEV V3 fresnel_refraction( V3 dir_i, V3 exit_nor, double trix )
 }
 
 /* ---- node access ---- */
-DEV bool node_has_env( NodeP n ) { return ( n->flags & ACN_NODE_HAS_ENVELOPE ) != 0; }
-DEV M3 node_rax( NodeP n )
+template< class NP > DEV bool node_has_env( NP n ) { return ( n->flags & ACN_NODE_HAS_ENVELOPE ) != 0; }
+template< class NP > DEV M3 node_rax( NP n )
 {
     M3 m;
     m.x = ld3( n->rax ); m.y = ld3( n->rax + 3 ); m.z = ld3( n->rax + 6 );
@@ -376,7 +392,7 @@ DEV M3 node_rax( NodeP n )
 /* envelope_s_ray_hits (objects.c:90-93) = sphere_ray_hit( ... ) < f3_inf.  Only the predicate is needed: by
  * gmath.h:64-83 the offset is finite exactly when s*s >= q and ( s < 0 or q < 0 ) -- the square root of the
  * non-negative discriminant is finite for finite inputs -- so the sqrt is not evaluated. */
-DEV bool env_ray_hits( NodeP n, V3 rp, V3 rd )
+template< class NP > DEV bool env_ray_hits( NP n, V3 rp, V3 rd )
 {
     V3 p = v_sub( rp, ld3( n->env_pos ) );
     double r = n->env_radius;
@@ -386,10 +402,10 @@ DEV bool env_ray_hits( NodeP n, V3 rp, V3 rd )
     if( s2 < q ) return false;
     return ( s < 0 && q > 0 ) || ( s < 0 || q < 0 );
 }
-DEV int env_side( NodeP n, V3 pos ) { return sphere_observer_side( ld3( n->env_pos ), n->env_radius, pos ); }
+template< class NP > DEV int env_side( NP n, V3 pos ) { return sphere_observer_side( ld3( n->env_pos ), n->env_radius, pos ); }
 
 /* ---- distance.c:39-42, 83-92 ---- */
-DEV double sdf_eval( NodeP n, V3 pos )
+template< class NP > DEV double sdf_eval( NP n, V3 pos )
 {
     if( n->sdf_kind == ACN_SDF_TORUS )
     {
@@ -405,7 +421,7 @@ DEV double sdf_eval( NodeP n, V3 pos )
 }
 
 /* ---- leaves ---- */
-DEV double squaroid_ray_hit( NodeP o, V3 rp, V3 rd, bool want_nor, V3* p_nor )   /* objects.c:778-821 */
+template< class NP > DEV double squaroid_ray_hit( NP o, V3 rp, V3 rd, bool want_nor, V3* p_nor )   /* objects.c:778-821 */
 {
     M3 rax = node_rax( o );
     double oa = o->prm[ 0 ], ob = o->prm[ 1 ], oc = o->prm[ 2 ], orr = o->prm[ 3 ];
@@ -443,15 +459,15 @@ DEV double squaroid_ray_hit( NodeP o, V3 rp, V3 rd, bool want_nor, V3* p_nor )  
     return a - F3_EPS;
 }
 
-DEV int squaroid_side( NodeP o, V3 pos )   /* objects.c:823-827 */
+template< class NP > DEV int squaroid_side( NP o, V3 pos )   /* objects.c:823-827 */
 {
     M3 rax = node_rax( o );
     V3 p = m_mlv( rax, v_sub( pos, ld3( o->pos ) ) );
     return ( o->prm[ 0 ] * p.x * p.x + o->prm[ 1 ] * p.y * p.y + o->prm[ 2 ] * p.z * p.z + o->prm[ 3 ] ) > 0 ? 1 : -1;
 }
 
-template< class CT >
-DEVN double distance_ray_hit( NodeP o, V3 rp, V3 rd, bool want_nor, V3* p_nor, CT* cnt )   /* objects.c:903-959 */
+template< class NP, class CT >
+DEVN double distance_ray_hit( NP o, V3 rp, V3 rd, bool want_nor, V3* p_nor, CT* cnt )   /* objects.c:903-959 */
 {
     M3 rax = node_rax( o );
     double inv_scale = o->prm[ 0 ];
@@ -511,7 +527,7 @@ DEVN double distance_ray_hit( NodeP o, V3 rp, V3 rd, bool want_nor, V3* p_nor, C
     return F3_INF;
 }
 
-DEV int distance_side( NodeP o, V3 pos )   /* objects.c:961-966 */
+template< class NP > DEV int distance_side( NP o, V3 pos )   /* objects.c:961-966 */
 {
     if( node_has_env( o ) && env_side( o, pos ) == 1 ) return 1;
     M3 rax = node_rax( o );
@@ -524,8 +540,8 @@ DEV int distance_side( NodeP o, V3 pos )   /* objects.c:961-966 */
  * in registers; the scratch stack is touched only when a composite is nested inside a composite. */
 struct SideFrame { int node; int pc; V3 pos; };
 
-template< class CT >
-DEV_SIDE int obj_side_dev( SceneRef sc, int root, V3 pos, CT* cnt )
+template< class SR, class CT >
+DEV_SIDE int obj_side_dev( SR sc, int root, V3 pos, CT* cnt )
 {
     SideFrame st[ ACN_CSG_MAX_DEPTH ];
     SideFrame cur;
@@ -536,7 +552,7 @@ DEV_SIDE int obj_side_dev( SceneRef sc, int root, V3 pos, CT* cnt )
     for( ;; )
     {
         /* EVAL( node, pos ) */
-        NodeP n = &sc.nodes[ node ];
+        auto n = &sc.nodes[ node ];
         cnt->inc( CNT_SIDE );
         bool have = true;
         int type = n->type;
@@ -577,7 +593,7 @@ DEV_SIDE int obj_side_dev( SceneRef sc, int root, V3 pos, CT* cnt )
         while( have )
         {
             if( depth == 0 ) return r;
-            NodeP fn = &sc.nodes[ cur.node ];
+            auto fn = &sc.nodes[ cur.node ];
             int ftype = fn->type;
             bool done = true;
             if( ftype == ACN_NEG ) r = -r;                                   /* objects.c:1341-1344 */
@@ -615,7 +631,7 @@ struct HitFrame
     V3 rp;            /* origin of the ray this call received */
 };
 
-DEV V3 roughness_normal( NodeP hdr, V3 n, V3 hit_pos )   /* objects.c:267-282 */
+template< class NP > DEV V3 roughness_normal( NP hdr, V3 n, V3 hit_pos )   /* objects.c:267-282 */
 {
     uint64_t rv = v_random_seed( hit_pos, 1246 );
     double f;
@@ -628,8 +644,8 @@ DEV V3 roughness_normal( NodeP hdr, V3 n, V3 hit_pos )   /* objects.c:267-282 */
     return v_of_length( n, 1.0 );
 }
 
-template< class CT >
-DEV_HIT double obj_ray_hit_dev( SceneRef sc, int root, V3 rp, V3 rd, bool want_nor, V3* out_nor, CT* cnt )
+template< class SR, class CT >
+DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3* out_nor, CT* cnt )
 {
     HitFrame st[ ACN_CSG_MAX_DEPTH ];
     HitFrame cur;
@@ -641,7 +657,7 @@ DEV_HIT double obj_ray_hit_dev( SceneRef sc, int root, V3 rp, V3 rd, bool want_n
     for( ;; )
     {
         /* ---- EVAL( node, rp, rd ) ---- */
-        NodeP n = &sc.nodes[ node ];
+        auto n = &sc.nodes[ node ];
         cnt->inc( CNT_OBJ_HIT );
         bool have = true;
         int type = n->type;
@@ -695,7 +711,7 @@ DEV_HIT double obj_ray_hit_dev( SceneRef sc, int root, V3 rp, V3 rd, bool want_n
                 if( want_nor && ret_a < F3_INF ) *out_nor = ret_n;
                 return ret_a;
             }
-            NodeP fn = &sc.nodes[ cur.node ];
+            auto fn = &sc.nodes[ cur.node ];
             int ftype = fn->type;
             bool done = true;
             if( ftype == ACN_NEG )   /* objects.c:1329-1339 */
@@ -802,15 +818,15 @@ DEV_HIT double obj_ray_hit_dev( SceneRef sc, int root, V3 rp, V3 rd, bool want_n
 /* Generic (per-lane indices) closest hit inside compound `cmp`, recursing into nested compounds with an explicit
  * stack. limit: stop as soon as a hit <= limit is found (any-hit for occlusion: "compound_s_ray_hit( matter ) > a"
  * is false iff some element hits at <= a). */
-template< class CT >
-DEVN double compound_ray_hit_dev( SceneRef sc, int cmp, V3 rp, V3 rd, bool want_nor, V3* p_nor, int* hit_obj,
+template< class SR, class CT >
+DEVN double compound_ray_hit_dev( SR sc, int cmp, V3 rp, V3 rd, bool want_nor, V3* p_nor, int* hit_obj,
                                   double limit, CT* cnt )
 {
     int st_i[ ACN_CMP_MAX_DEPTH ], st_end[ ACN_CMP_MAX_DEPTH ];
     int sp = 0;
     double min_a = F3_INF;
     {
-        NodeP o = &sc.nodes[ cmp ];
+        auto o = &sc.nodes[ cmp ];
         if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) return F3_INF;
         st_i[ 0 ] = o->child0; st_end[ 0 ] = o->child0 + o->child1; sp = 1;
     }
@@ -818,7 +834,7 @@ DEVN double compound_ray_hit_dev( SceneRef sc, int cmp, V3 rp, V3 rd, bool want_
     {
         if( st_i[ sp - 1 ] >= st_end[ sp - 1 ] ) { sp--; continue; }
         int element = sc.elems[ st_i[ sp - 1 ]++ ];
-        NodeP e = &sc.nodes[ element ];
+        auto e = &sc.nodes[ element ];
         if( e->type == ACN_COMPOUND )
         {
             if( node_has_env( e ) && !env_ray_hits( e, rp, rd ) ) continue;
@@ -847,10 +863,10 @@ DEVN double compound_ray_hit_dev( SceneRef sc, int cmp, V3 rp, V3 rd, bool want_
  *   - pair_inside: one child surely outside -> it returns f3_inf and classifies every point of the ray as outside, so
  *     neither the direct candidates nor the alternating walk can accept a hit (objects.c:1057-1092), side != -2.
  * Complements and scale wrappers are never pruned.  Expanded D levels deep. */
-template< int D >
-DEV bool surely_outside( const DevScene& sc, int node, V3 rp, V3 rd )
+template< int D, class SC >
+DEV bool surely_outside( const SC& sc, int node, V3 rp, V3 rd )
 {
-    NodeP n = &sc.nodes[ node ];
+    auto n = &sc.nodes[ node ];
     if( node_has_env( n ) && !env_ray_hits( n, rp, rd ) ) return true;
     if constexpr( D > 0 )
     {
@@ -866,10 +882,10 @@ DEV bool surely_outside( const DevScene& sc, int node, V3 rp, V3 rd )
  * through the scalar cache into SGPRs and the type dispatch is a scalar branch): obj_ray_hit (objects.c:261-284)
  * for objects -- plane / sphere / squaroid inline, CSG and SDF objects through the hit machine -- and
  * compound_s_ray_hit for nested compounds. */
-template< bool NOR, class CT >
-DEV double element_hit( const DevScene& sc, int e, V3 rp, V3 rd, V3* nor, int* hit_obj, double limit, CT* cnt )
+template< bool NOR, class SC, class CT >
+DEV double element_hit( const SC& sc, int e, V3 rp, V3 rd, V3* nor, int* hit_obj, double limit, CT* cnt )
 {
-    NodeP n = &sc.nodes[ e ];
+    auto n = &sc.nodes[ e ];
     int type = n->type;
     if( type == ACN_COMPOUND ) return compound_ray_hit_dev( sref( sc ), e, rp, rd, NOR, nor, hit_obj, limit, cnt );
     *hit_obj = e;
@@ -890,10 +906,10 @@ DEV double element_hit( const DevScene& sc, int e, V3 rp, V3 rd, V3* nor, int* h
 }
 
 /* compound_s_ray_hit on a root compound, any-hit form for occlusion tests: true iff some element hits at <= limit */
-template< class CT >
-DEV bool root_occluded( const DevScene& sc, int cmp, V3 rp, V3 rd, double limit, CT* cnt )
+template< class SC, class CT >
+DEV bool root_occluded( const SC& sc, int cmp, V3 rp, V3 rd, double limit, CT* cnt )
 {
-    NodeP o = &sc.nodes[ cmp ];
+    auto o = &sc.nodes[ cmp ];
     if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) return false;
     int first = o->child0, count = o->child1;
     for( int i = 0; i < count; i++ )
@@ -909,10 +925,10 @@ DEV bool root_occluded( const DevScene& sc, int cmp, V3 rp, V3 rd, double limit,
 struct Trans { V3 exit_nor; int exit_obj; int enter_obj; };
 
 /* compound_s_ray_trans_hit on a root compound (compound.c:246-299) */
-template< class CT >
-DEV double root_trans_hit( const DevScene& sc, int cmp, V3 rp, V3 rd, Trans* trans, CT* cnt )
+template< class SC, class CT >
+DEV double root_trans_hit( const SC& sc, int cmp, V3 rp, V3 rd, Trans* trans, CT* cnt )
 {
-    NodeP o = &sc.nodes[ cmp ];
+    auto o = &sc.nodes[ cmp ];
     cnt->inc( CNT_TRANS_RAY );
     if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) return F3_INF;
     double min_a = F3_INF;
@@ -955,8 +971,8 @@ DEV double root_trans_hit( const DevScene& sc, int cmp, V3 rp, V3 rd, Trans* tra
  * (obj_ray_hit then returns f3_inf for it, objects.c:264). ---- */
 DEV bool is_fast_type( int type ) { return type >= ACN_PLANE && type <= ACN_SQUAROID; }
 
-template< bool NOR, class CT >
-DEV double leaf_element_hit( NodeP n, int type, V3 rp, V3 rd, V3* nor, CT* cnt )
+template< bool NOR, class NP, class CT >
+DEV double leaf_element_hit( NP n, int type, V3 rp, V3 rd, V3* nor, CT* cnt )
 {
     cnt->inc( CNT_OBJ_HIT );
     if( node_has_env( n ) && !env_ray_hits( n, rp, rd ) ) return F3_INF;
@@ -969,17 +985,17 @@ DEV double leaf_element_hit( NodeP n, int type, V3 rp, V3 rd, V3* nor, CT* cnt )
 }
 
 /* 0: not occluded, 1: occluded, 2: undecided (hard) */
-template< class CT >
-DEV int root_occluded_fast( const DevScene& sc, int cmp, V3 rp, V3 rd, double limit, CT* cnt )
+template< class SC, class CT >
+DEV int root_occluded_fast( const SC& sc, int cmp, V3 rp, V3 rd, double limit, CT* cnt )
 {
-    NodeP o = &sc.nodes[ cmp ];
+    auto o = &sc.nodes[ cmp ];
     if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) return 0;
     int first = o->child0, count = o->child1;
     bool hard = false;
     for( int i = 0; i < count; i++ )
     {
         int element = __builtin_amdgcn_readfirstlane( sc.elems[ first + i ] );
-        NodeP n = &sc.nodes[ element ];
+        auto n = &sc.nodes[ element ];
         int type = n->type;
         if( is_fast_type( type ) )
         {
@@ -996,10 +1012,10 @@ DEV int root_occluded_fast( const DevScene& sc, int cmp, V3 rp, V3 rd, double li
 }
 
 /* compound_s_ray_trans_hit on a root compound; *hard is set when the query must be redone by the full traversal */
-template< class CT >
-DEV double root_trans_hit_fast( const DevScene& sc, int cmp, V3 rp, V3 rd, Trans* trans, bool* hard, CT* cnt )
+template< class SC, class CT >
+DEV double root_trans_hit_fast( const SC& sc, int cmp, V3 rp, V3 rd, Trans* trans, bool* hard, CT* cnt )
 {
-    NodeP o = &sc.nodes[ cmp ];
+    auto o = &sc.nodes[ cmp ];
     *hard = false;
     if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) { cnt->inc( CNT_TRANS_RAY ); return F3_INF; }
     double min_a = F3_INF;
@@ -1008,7 +1024,7 @@ DEV double root_trans_hit_fast( const DevScene& sc, int cmp, V3 rp, V3 rd, Trans
     for( int i = 0; i < count; i++ )
     {
         int element = __builtin_amdgcn_readfirstlane( sc.elems[ first + i ] );
-        NodeP n = &sc.nodes[ element ];
+        auto n = &sc.nodes[ element ];
         int type = n->type;
         if( !is_fast_type( type ) )
         {
@@ -1045,8 +1061,8 @@ DEV double root_trans_hit_fast( const DevScene& sc, int cmp, V3 rp, V3 rd, Trans
     return min_a;
 }
 
-template< class CT >
-DEV double scene_trans_hit_dev( const DevScene& sc, V3 rp, V3 rd, Trans* trans, CT* cnt )   /* scene.c:362-382 */
+template< class SC, class CT >
+DEV double scene_trans_hit_dev( const SC& sc, V3 rp, V3 rd, Trans* trans, CT* cnt )   /* scene.c:362-382 */
 {
     double min_a = F3_INF;
     double a;
@@ -1075,7 +1091,7 @@ DEV void sphere_fov( V3 center, double radius, V3 pos, V3* dir, double* cos_rs )
     *cos_rs = ( diff_sqr > radius_sqr ) ? acn_sqrt( 1.0 - ( radius_sqr / diff_sqr ) ) : -1;
 }
 
-DEV void obj_fov_dev( NodeP o, V3 pos, V3* dir, double* cos_rs )
+template< class NP > DEV void obj_fov_dev( NP o, V3 pos, V3* dir, double* cos_rs )
 {
     if( o->type == ACN_PLANE )
     {
@@ -1122,7 +1138,7 @@ DEV V3 cl_sat( V3 o, double gamma )
 }
 
 /* camera ray for a sample position: scene.c:980-990 */
-DEV void camera_ray( const DevScene& sc, double monitor_x, double monitor_y, V3* rp, V3* rd )
+template< class SC > DEV void camera_ray( const SC& sc, double monitor_x, double monitor_y, V3* rp, V3* rd )
 {
     uint64_t width = sc.prm.image_width, height = sc.prm.image_height;
     double z = sc.unit_f * ( ( height >> 1 ) - monitor_y );

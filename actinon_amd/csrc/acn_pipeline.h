@@ -344,6 +344,17 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
 #define ACN_SCENE_ARGS( h ) ( h )->dev, ( h )->d_nodes, ( h )->d_mats, ( h )->d_elems
 #define ACN_SCENE_VIEW    DevScene sc = sc_in; sc.nodes = ( NodeP )p_nodes; sc.mats = ( MatP )p_mats; sc.elems = ( ElemP )p_elems; sc.flags = p_counts + QC_FLAGS;
 
+/* LDS staging of the node array (kernels whose node reads are per-lane: the CSG machines).  The block copies the
+ * GNode array into dynamic shared memory once; per-lane node reads then are ds_read instead of global loads. */
+extern __shared__ __attribute__( ( aligned( 16 ) ) ) double acn_lds_raw[];
+#define ACN_STAGE_NODES( sc ) \
+    { \
+        const double* src_ = ( const double* )p_nodes; \
+        uint32_t words_ = ( sc ).n_nodes * ( uint32_t )( sizeof( GNode ) / sizeof( double ) ); \
+        for( uint32_t k_ = threadIdx.x; k_ < words_; k_ += blockDim.x ) acn_lds_raw[ k_ ] = src_[ k_ ]; \
+        __syncthreads(); \
+    }
+
 #define ACN_WALK_QUEUE_PARAMS DTask* __restrict__ p_tasks, uint32_t* __restrict__ p_idx0, uint32_t* __restrict__ p_idx1, \
     uint32_t* __restrict__ p_idx2, uint32_t* __restrict__ p_idx3, uint32_t* __restrict__ p_counts, uint32_t task_cap, \
     RayTask* __restrict__ p_rays_out, uint32_t ray_cap
@@ -356,14 +367,11 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
 /* One pass of the specular walk: one lane per ray.  PRIMARY: the rays are the camera rays of the sample positions
  * (lum_machine_s_func, scene.c:976-1011); otherwise they come from the ray queue the previous pass filled.  Each ray
  * is traced (scene_s_trans_hit) and its hit shaded; what it spawns goes to the next pass / the shading-task queues. */
-template< bool PRIMARY, bool COUNT >
-__global__ __launch_bounds__( 256, ACN_WALK_WAVES )
-void k_trace_rays( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __restrict__ rays_in,
-                   const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n,
-                   unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
+template< bool PRIMARY, bool COUNT, class SCL >
+DEV void trace_rays_body( const DevScene& sc, const SCL& scl, const Queues& q, const RayTask* __restrict__ rays_in,
+                          const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n,
+                          unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
-    ACN_SCENE_VIEW
-    ACN_WALK_QUEUE_VIEW
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     Cnt< COUNT > cnt;
     cnt.clear();
@@ -395,7 +403,7 @@ void k_trace_rays( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __res
     Trans trans;
     trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
     double offs = F3_INF;
-    if( live ) offs = scene_trans_hit_dev( sc, t.p, t.d, &trans, &cnt );
+    if( live ) offs = scene_trans_hit_dev( scl, t.p, t.d, &trans, &cnt );
     bool hit = live && offs < F3_INF;
     if( live && !hit )
     {
@@ -406,6 +414,25 @@ void k_trace_rays( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __res
     shade_hit( sc, q, t.p, t.d, hit ? offs : 0.0, trans, hit ? t.depth : 0, t.intensity, t.T, t.pixel, acc, &cnt );
     if( live ) pixel_add( accum, t.pixel, acc );
     wave_add_counters( counters, cnt );
+}
+
+template< bool PRIMARY, bool COUNT, bool LDS >
+__global__ __launch_bounds__( 256, ACN_WALK_WAVES )
+void k_trace_rays( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __restrict__ rays_in,
+                   const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n,
+                   unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
+{
+    ACN_SCENE_VIEW
+    ACN_WALK_QUEUE_VIEW
+    if constexpr( LDS )
+    {
+        ACN_STAGE_NODES( sc )
+        trace_rays_body< PRIMARY, COUNT >( sc, scene_rebind( sc, ( LdsNodeP )acn_lds_raw ), q, rays_in, pos_xy, first_pixel, base, n, accum, counters );
+    }
+    else
+    {
+        trace_rays_body< PRIMARY, COUNT >( sc, sc, q, rays_in, pos_xy, first_pixel, base, n, accum, counters );
+    }
 }
 
 /* first pass of a level >= 1: one lane per path-sample hit (the recursive scene_s_lum call of scene.c:610) */
@@ -620,7 +647,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
 }
 
 /* the shadow rays k_shade could not decide inline: full occlusion test, one lane per ray */
-template< bool COUNT >
+template< bool COUNT, bool LDS >
 __global__ __launch_bounds__( 256, ACN_WALK_WAVES )
 void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint32_t n, uint32_t* __restrict__ p_counts,
                     unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
@@ -629,16 +656,20 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     Cnt< COUNT > cnt;
     cnt.clear();
+    if constexpr( LDS ) ACN_STAGE_NODES( sc )
     if( i < n )
     {
         HardShadow r = recs[ i ];
-        if( !root_occluded( sc, sc.matter_root, r.pos, r.d, r.limit, &cnt ) ) pixel_add( accum, r.pixel, r.contrib );
+        bool occ;
+        if constexpr( LDS ) occ = root_occluded( scene_rebind( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, r.limit, &cnt );
+        else                occ = root_occluded( sc, sc.matter_root, r.pos, r.d, r.limit, &cnt );
+        if( !occ ) pixel_add( accum, r.pixel, r.contrib );
     }
     wave_add_counters( counters, cnt );
 }
 
 /* the path rays k_shade could not finish inline: full transition hit; hits join the next level's HitRec queue */
-template< bool COUNT >
+template< bool COUNT, bool LDS >
 __global__ __launch_bounds__( 256, ACN_WALK_WAVES )
 void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t n, HitRec* __restrict__ p_children, uint32_t child_cap,
                   uint32_t* __restrict__ p_counts, unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
@@ -647,6 +678,7 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     Cnt< COUNT > cnt;
     cnt.clear();
+    if constexpr( LDS ) ACN_STAGE_NODES( sc )
     bool hit = false;
     HardPath r;
     Trans trans;
@@ -655,7 +687,8 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
     if( i < n )
     {
         r = recs[ i ];
-        a = root_trans_hit( sc, sc.matter_root, r.pos, r.d, &trans, &cnt );
+        if constexpr( LDS ) a = root_trans_hit( scene_rebind( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, &trans, &cnt );
+        else                a = root_trans_hit( sc, sc.matter_root, r.pos, r.d, &trans, &cnt );
         hit = a < sc.prm.max_path_length;
         if( !hit )
         {

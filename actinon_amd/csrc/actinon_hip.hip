@@ -38,6 +38,7 @@ struct acn_scene_handle
     unsigned long long* d_accum = nullptr;  size_t accum_cap = 0;
     unsigned long long* d_counters = nullptr;
     std::vector< StageEvents > events;  size_t events_used = 0;
+    size_t lds_bytes = 0;                      /* > 0: the node array fits the LDS staging budget */
     bool leaf_lights = true;                   /* every light element is a plane / sphere */
     bool count_work = false;                   /* ACN_OPT_COUNT_WORK of the current call */
     uint64_t launches[ 4 ] = { 0, 0, 0, 0 };   /* walk, shade, finalize, hard-ray kernels */
@@ -346,6 +347,12 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
             if( t != ACN_PLANE && t != ACN_SPHERE ) h->leaf_lights = false;
         }
     }
+    {
+        size_t lds_max = 65536;
+        if( const char* e = getenv( "ACN_LDS_MAX" ) ) lds_max = ( size_t )atoll( e );
+        size_t need = sizeof( GNode ) * ( size_t )scene->n_nodes;
+        h->lds_bytes = need <= lds_max ? need : 0;
+    }
     h->dev.flags = h->q.counts + QC_FLAGS;
     HIP_TRY_H( hipMemset( h->q.counts, 0, sizeof( uint32_t ) * QC_N ) );
     /* camera basis on the device so that it shares the device's arithmetic */
@@ -493,14 +500,12 @@ static int walk_passes( acn_scene_handle* h, uint32_t n_in, int* cur, hipStream_
         int in = *cur, out = 1 - in;
         HIP_TRY( hipMemsetAsync( h->q.counts + QC_RAYS, 0, sizeof( uint32_t ), stream ) );
         if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
-        if( h->count_work )
-            hipLaunchKernelGGL( ( k_trace_rays< false, true > ), dim3( ( n_in + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                                ACN_WALK_QUEUE_ARGS( h, out ), ( const RayTask* )h->rays[ in ], ( const double* )nullptr, ( size_t )0, 0u, n_in,
-                                h->d_accum, h->d_counters );
-        else
-            hipLaunchKernelGGL( ( k_trace_rays< false, false > ), dim3( ( n_in + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                                ACN_WALK_QUEUE_ARGS( h, out ), ( const RayTask* )h->rays[ in ], ( const double* )nullptr, ( size_t )0, 0u, n_in,
-                                h->d_accum, h->d_counters );
+#define ACN_LAUNCH_TRACE( P, C, L, N, ... ) hipLaunchKernelGGL( ( k_trace_rays< P, C, L > ), dim3( ( ( N ) + 255 ) / 256 ), dim3( 256 ), ( L ) ? h->lds_bytes : 0, stream, \
+            ACN_SCENE_ARGS( h ), __VA_ARGS__, h->d_accum, h->d_counters )
+#define ACN_DISPATCH_TRACE( P, N, ... ) do { \
+            if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_TRACE( P, true, true, N, __VA_ARGS__ ); else ACN_LAUNCH_TRACE( P, true, false, N, __VA_ARGS__ ); } \
+            else                { if( h->lds_bytes ) ACN_LAUNCH_TRACE( P, false, true, N, __VA_ARGS__ ); else ACN_LAUNCH_TRACE( P, false, false, N, __VA_ARGS__ ); } } while( 0 )
+        ACN_DISPATCH_TRACE( false, n_in, ACN_WALK_QUEUE_ARGS( h, out ), ( const RayTask* )h->rays[ in ], ( const double* )nullptr, ( size_t )0, 0u, n_in );
         HIP_TRY( hipGetLastError() );
         if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
         if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
@@ -522,12 +527,7 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
     HIP_TRY( hipMemsetAsync( h->q.counts, 0, sizeof( uint32_t ) * QC_N, stream ) );
     /* level 0, pass 0: the camera rays */
     if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
-    if( h->count_work )
-        hipLaunchKernelGGL( ( k_trace_rays< true, true > ), dim3( ( cnt + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                            ACN_WALK_QUEUE_ARGS( h, cur ), ( const RayTask* )nullptr, d_pos_xy, first_pixel, base, cnt, h->d_accum, h->d_counters );
-    else
-        hipLaunchKernelGGL( ( k_trace_rays< true, false > ), dim3( ( cnt + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                            ACN_WALK_QUEUE_ARGS( h, cur ), ( const RayTask* )nullptr, d_pos_xy, first_pixel, base, cnt, h->d_accum, h->d_counters );
+    ACN_DISPATCH_TRACE( true, cnt, ACN_WALK_QUEUE_ARGS( h, cur ), ( const RayTask* )nullptr, d_pos_xy, first_pixel, base, cnt );
     HIP_TRY( hipGetLastError() );
     if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
     if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
@@ -558,24 +558,20 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
             if( n_hs )
             {
                 if( ( st = stage_begin( h, 3, stream ) ) != ACN_OK ) return st;
-                if( h->count_work )
-                    hipLaunchKernelGGL( k_hard_shadow< true >, dim3( ( n_hs + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                                        ( const HardShadow* )h->q.hard_shadow, n_hs, h->q.counts, h->d_accum, h->d_counters );
-                else
-                    hipLaunchKernelGGL( k_hard_shadow< false >, dim3( ( n_hs + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                                        ( const HardShadow* )h->q.hard_shadow, n_hs, h->q.counts, h->d_accum, h->d_counters );
+#define ACN_LAUNCH_HS( C, L ) hipLaunchKernelGGL( ( k_hard_shadow< C, L > ), dim3( ( n_hs + 255 ) / 256 ), dim3( 256 ), ( L ) ? h->lds_bytes : 0, stream, ACN_SCENE_ARGS( h ), \
+                    ( const HardShadow* )h->q.hard_shadow, n_hs, h->q.counts, h->d_accum, h->d_counters )
+                if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_HS( true, true ); else ACN_LAUNCH_HS( true, false ); }
+                else                { if( h->lds_bytes ) ACN_LAUNCH_HS( false, true ); else ACN_LAUNCH_HS( false, false ); }
                 HIP_TRY( hipGetLastError() );
                 if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
             }
             if( n_hp )
             {
                 if( ( st = stage_begin( h, 3, stream ) ) != ACN_OK ) return st;
-                if( h->count_work )
-                    hipLaunchKernelGGL( k_hard_path< true >, dim3( ( n_hp + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                                        ( const HardPath* )h->q.hard_path, n_hp, h->q.children, h->q.child_cap, h->q.counts, h->d_accum, h->d_counters );
-                else
-                    hipLaunchKernelGGL( k_hard_path< false >, dim3( ( n_hp + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                                        ( const HardPath* )h->q.hard_path, n_hp, h->q.children, h->q.child_cap, h->q.counts, h->d_accum, h->d_counters );
+#define ACN_LAUNCH_HP( C, L ) hipLaunchKernelGGL( ( k_hard_path< C, L > ), dim3( ( n_hp + 255 ) / 256 ), dim3( 256 ), ( L ) ? h->lds_bytes : 0, stream, ACN_SCENE_ARGS( h ), \
+                    ( const HardPath* )h->q.hard_path, n_hp, h->q.children, h->q.child_cap, h->q.counts, h->d_accum, h->d_counters )
+                if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_HP( true, true ); else ACN_LAUNCH_HP( true, false ); }
+                else                { if( h->lds_bytes ) ACN_LAUNCH_HP( false, true ); else ACN_LAUNCH_HP( false, false ); }
                 HIP_TRY( hipGetLastError() );
                 if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
                 if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
