@@ -35,7 +35,8 @@ HOST_SYMBOLS = ["acn_rotx", "acn_roty", "acn_rotz", "acn_obj_plane_s_create", "a
                 "acn_obj_set_color", "acn_obj_set_transparency", "acn_obj_set_refractive_index", "acn_obj_set_radiance",
                 "acn_obj_set_fresnel_reflectivity", "acn_obj_set_chromatic_reflectivity",
                 "acn_obj_set_diffuse_reflectivity", "acn_obj_set_sigma", "acn_obj_set_surface_roughness",
-                "acn_obj_set_material", "acn_obj_set_envelope", "acn_obj_set_auto_envelope", "acn_obj_radiance",
+                "acn_obj_set_material", "acn_obj_set_texture_field_plain", "acn_obj_set_texture_field_chess",
+                "acn_obj_clear_texture_field", "acn_obj_set_envelope", "acn_obj_set_auto_envelope", "acn_obj_radiance",
                 "acn_obj_get_envelope", "acn_compound_s_create", "acn_compound_s_push", "acn_compound_s_get_size",
                 "acn_compound_s_clear", "acn_compound_s_set_sphere_envelopes", "acn_scene_s_create",
                 "acn_scene_s_discard", "acn_scene_s_clear", "acn_scene_s_push", "acn_scene_s_objects",
@@ -111,6 +112,12 @@ for _n in ["refractive_index", "radiance", "fresnel_reflectivity", "chromatic_re
     f = getattr(host, "acn_obj_set_" + _n)
     f.argtypes = [vp, C.c_double]
     f.restype = None
+host.acn_obj_set_texture_field_plain.argtypes = [vp, abi.V3]
+host.acn_obj_set_texture_field_plain.restype = None
+host.acn_obj_set_texture_field_chess.argtypes = [vp, abi.V3, abi.V3, C.c_double]
+host.acn_obj_set_texture_field_chess.restype = None
+host.acn_obj_clear_texture_field.argtypes = [vp]
+host.acn_obj_clear_texture_field.restype = None
 host.acn_obj_set_material.argtypes = [vp, C.c_char_p]
 host.acn_obj_set_envelope.argtypes = [vp, abi.V3, C.c_double]
 host.acn_obj_set_envelope.restype = None

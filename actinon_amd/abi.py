@@ -1,7 +1,7 @@
 """ctypes mirror of include/actinon_hip.h and include/acn_scene.h (layout only, no logic)."""
 import ctypes as C
 
-ACN_ABI_VERSION = 1
+ACN_ABI_VERSION = 2
 ACN_OPT_LINEAR_OUT = 1
 ACN_OPT_COUNT_WORK = 2
 
@@ -32,10 +32,16 @@ class Params(C.Structure):
                 ("experimental_level", C.c_int64)]
 
 
+class Texture(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("color1", C.c_double * 3), ("color2", C.c_double * 3),
+                ("scale", C.c_double)]
+
+
 class FlatScene(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("n_nodes", C.c_uint32), ("n_elems", C.c_uint32),
                 ("light_root", C.c_int32), ("matter_root", C.c_int32), ("reserved", C.c_uint32),
-                ("nodes", C.POINTER(Node)), ("elems", C.POINTER(C.c_int32)), ("params", Params)]
+                ("nodes", C.POINTER(Node)), ("elems", C.POINTER(C.c_int32)), ("params", Params),
+                ("n_textures", C.c_uint32), ("reserved2", C.c_uint32), ("textures", C.POINTER(Texture))]
 
 
 class RenderOpts(C.Structure):

@@ -277,4 +277,125 @@ ACN_HD double acn_pow( double x, double y )
     return acn_exp( y * acn_log( x ) );
 }
 
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* asin / atan / atan2: only the texture projection of a sphere uses them (src/objects.c:602-617); same fdlibm forms */
+ACN_HD double acn_asin( double x )
+{
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17, pio4_hi = 7.85398163397448278999e-01;
+    const double pS0 =  1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 =  2.01212532134862925881e-01,
+                 pS3 = -4.00555345006794114027e-02, pS4 =  7.91534994289814532176e-04, pS5 =  3.47933107596021167570e-05,
+                 qS1 = -2.40339491173441421878e+00, qS2 =  2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
+                 qS4 =  7.70381505559019352791e-02;
+    double ax = acn_fabs( x );
+    if( !( ax < 1.0 ) )
+    {
+        if( ax == 1.0 ) return x * pio2_hi + x * pio2_lo;
+        return ( x - x ) / ( x - x );
+    }
+    if( ax < 0.5 )
+    {
+        if( ax < 7.450580596923828e-09 ) return x; /* 2^-27 */
+        double t = x * x;
+        double p = t * ( pS0 + t * ( pS1 + t * ( pS2 + t * ( pS3 + t * ( pS4 + t * pS5 ) ) ) ) );
+        double q = 1.0 + t * ( qS1 + t * ( qS2 + t * ( qS3 + t * qS4 ) ) );
+        return x + x * ( p / q );
+    }
+    double w = 1.0 - ax;
+    double t = w * 0.5;
+    double p = t * ( pS0 + t * ( pS1 + t * ( pS2 + t * ( pS3 + t * ( pS4 + t * pS5 ) ) ) ) );
+    double q = 1.0 + t * ( qS1 + t * ( qS2 + t * ( qS3 + t * qS4 ) ) );
+    double s = acn_sqrt( t );
+    double r;
+    if( ax >= 0.975 )
+    {
+        w = p / q;
+        r = pio2_hi - ( 2.0 * ( s + s * w ) - pio2_lo );
+    }
+    else
+    {
+        double ws = acn_bits_f64( acn_f64_bits( s ) & 0xFFFFFFFF00000000ull );
+        double c = ( t - ws * ws ) / ( s + ws );
+        double rr = p / q;
+        double pp = 2.0 * s * rr - ( pio2_lo - 2.0 * c );
+        double qq = pio4_hi - 2.0 * ws;
+        r = pio4_hi - ( pp - qq );
+    }
+    return ( x > 0 ) ? r : -r;
+}
+
+ACN_HD double acn_atan( double x )
+{
+    const double atanhi[ 4 ] = { 4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01, 1.57079632679489655800e+00 };
+    const double atanlo[ 4 ] = { 2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17, 6.12323399573676603587e-17 };
+    const double aT0 =  3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01, aT2 =  1.42857142725034663711e-01,
+                 aT3 = -1.11111104054623557880e-01, aT4 =  9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
+                 aT6 =  6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02, aT8 =  4.97687799461593236017e-02,
+                 aT9 = -3.65315727442169155270e-02, aT10 = 1.62858201153657823623e-02;
+    if( x != x ) return x;
+    double ax = acn_fabs( x );
+    int id;
+    double hi = 0, lo = 0;
+    if( ax >= 7.378697629483821e+19 )   /* 2^66 */
+    {
+        double r = atanhi[ 3 ] + atanlo[ 3 ];
+        return ( x < 0 ) ? -r : r;
+    }
+    if( ax < 0.4375 )
+    {
+        if( ax < 1.862645149230957e-09 ) return x; /* 2^-29 */
+        id = -1;
+        ax = ax;
+    }
+    else if( ax < 1.1875 )
+    {
+        if( ax < 0.6875 ) { id = 0; ax = ( 2.0 * ax - 1.0 ) / ( 2.0 + ax ); }
+        else              { id = 1; ax = ( ax - 1.0 ) / ( ax + 1.0 ); }
+    }
+    else
+    {
+        if( ax < 2.4375 ) { id = 2; ax = ( ax - 1.5 ) / ( 1.0 + 1.5 * ax ); }
+        else              { id = 3; ax = -1.0 / ax; }
+    }
+    if( id >= 0 ) { hi = atanhi[ id ]; lo = atanlo[ id ]; }
+    double z = ax * ax;
+    double w = z * z;
+    double s1 = z * ( aT0 + w * ( aT2 + w * ( aT4 + w * ( aT6 + w * ( aT8 + w * aT10 ) ) ) ) );
+    double s2 = w * ( aT1 + w * ( aT3 + w * ( aT5 + w * ( aT7 + w * aT9 ) ) ) );
+    double r;
+    if( id < 0 ) r = ax - ax * ( s1 + s2 );
+    else         r = hi - ( ( ax * ( s1 + s2 ) - lo ) - ax );
+    return ( x < 0 ) ? -r : r;
+}
+
+ACN_HD double acn_atan2( double y, double x )
+{
+    const double pi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16;
+    if( x != x || y != y ) return x + y;
+    if( x == 1.0 ) return acn_atan( y );
+    int sy = ( acn_f64_bits( y ) >> 63 ) != 0;
+    int sx = ( acn_f64_bits( x ) >> 63 ) != 0;
+    if( y == 0.0 ) return sx ? ( sy ? -pi : pi ) : y;
+    if( x == 0.0 ) return sy ? -pi * 0.5 : pi * 0.5;
+    double ax = acn_fabs( x ), ay = acn_fabs( y );
+    const double inf = acn_bits_f64( 0x7FF0000000000000ull );
+    if( ax == inf )
+    {
+        if( ay == inf ) { double r = sx ? 3.0 * pi * 0.25 : pi * 0.25; return sy ? -r : r; }
+        double r = sx ? pi : 0.0;
+        return sy ? -r : r;
+    }
+    if( ay == inf ) return sy ? -pi * 0.5 : pi * 0.5;
+    double z;
+    double q = ay / ax;
+    if( q > 1.8446744073709552e+19 )        z = pi * 0.5 + 0.5 * pi_lo;   /* |y/x| > 2^64 */
+    else if( sx && q < 5.421010862427522e-20 ) z = 0.0;                    /* |y/x| < 2^-64, x < 0 */
+    else                                    z = acn_atan( q );
+    if( !sx ) return sy ? -z : z;
+    double r = pi - ( z - pi_lo );
+    return sy ? -r : r;
+}
+
+/* llrint(): round to nearest even (the default rounding mode), then convert */
+ACN_HD long long acn_llrint( double x ) { return ( long long )__builtin_rint( x ); }
+
 #endif /* ACN_DETMATH_H */

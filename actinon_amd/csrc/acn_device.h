@@ -86,6 +86,8 @@ struct GMat
     double diffuse_reflectivity;
     double sigma;
     double transparency[ 3 ];
+    int32_t texture;     /* index into the texture table, -1 = none */
+    int32_t pad_;
 };
 
 /* The scene arrays are read through the CONSTANT address space: they never change while a kernel runs, so a load
@@ -97,6 +99,7 @@ typedef const GNode   ACN_CONST* NodeP;
 typedef const GMat    ACN_CONST* MatP;
 typedef const int32_t ACN_CONST* ElemP;
 typedef const double  ACN_CONST* CDblP;
+typedef const acn_texture ACN_CONST* TexP;
 
 /* node array staged in LDS (per workgroup) for the kernels whose node accesses are per-lane */
 #define ACN_LDS __attribute__( ( address_space( 3 ) ) )
@@ -109,6 +112,7 @@ struct DevSceneT
     NP nodes;
     MatP  mats;
     ElemP elems;
+    TexP  textures;
     int32_t light_root, matter_root;
     uint32_t n_nodes, n_elems;
     acn_params prm;
@@ -124,7 +128,7 @@ template< class NP2 >
 __device__ __forceinline__ DevSceneT< NP2 > scene_rebind( const DevScene& sc, NP2 nodes )
 {
     DevSceneT< NP2 > r;
-    r.nodes = nodes; r.mats = sc.mats; r.elems = sc.elems;
+    r.nodes = nodes; r.mats = sc.mats; r.elems = sc.elems; r.textures = sc.textures;
     r.light_root = sc.light_root; r.matter_root = sc.matter_root; r.n_nodes = sc.n_nodes; r.n_elems = sc.n_elems;
     r.prm = sc.prm; r.camera_rotation = sc.camera_rotation; r.unit_f = sc.unit_f; r.flags = sc.flags;
     return r;
@@ -1123,6 +1127,39 @@ DEV double oren_nayar_weight( double weight, double theta_i, double on_a, double
     acn_sincos( ta, &s1, &c1 );
     acn_sincos( tb, &s2, &c2 );
     return weight * ( on_a + ( on_b * f_max( cos_phi, 0 ) * s1 * ( s2 / c2 ) ) );
+}
+
+/* obj_color (objects.c:411-422): texture field if present (textures.c:99-102, 142-148), else prp.color.
+ * obj_projection: plane objects.c:514-518, sphere :602-617, distance :893-896. */
+DEV V3 obj_color_dev( const DevScene& sc, int node, V3 pos )
+{
+    MatP m = &sc.mats[ node ];
+    int tex = m->texture;
+    if( tex < 0 ) return ld3( m->color );
+    TexP t = &sc.textures[ tex ];
+    if( t->kind == ACN_TXM_PLAIN ) return ld3( t->color1 );
+    NodeP o = &sc.nodes[ node ];
+    double px = 0, py = 0;
+    if( o->type == ACN_PLANE )
+    {
+        V3 p = v_sub( pos, ld3( o->pos ) );
+        px = v_mlv( p, ld3( o->rax ) );
+        py = v_mlv( p, ld3( o->rax + 3 ) );
+    }
+    else if( o->type == ACN_SPHERE )
+    {
+        V3 r = v_of_length( v_sub( pos, ld3( o->pos ) ), 1.0 );
+        double x = v_mlv( r, ld3( o->rax ) );
+        double y = v_mlv( r, v_mlx( ld3( o->rax + 6 ), ld3( o->rax ) ) );
+        double z = v_mlv( r, ld3( o->rax + 6 ) );
+        px = acn_atan2( x, y );
+        z = z >  1.0 ?  1.0 : z;
+        z = z < -1.0 ? -1.0 : z;
+        py = acn_asin( z );
+    }
+    long long x = acn_llrint( px * t->scale );
+    long long y = acn_llrint( py * t->scale );
+    return ( ( x ^ y ) & 1 ) ? ld3( t->color1 ) : ld3( t->color2 );
 }
 
 /* vectors.h:372-384 */

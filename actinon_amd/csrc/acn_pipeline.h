@@ -207,7 +207,7 @@ DEV void shade_hit( const DevScene& sc, const Queues& q, V3 rp, V3 rd, double of
     {
         double diff_sqr = v_diff_sqr( pos, ld3( sc.nodes[ trans.enter_obj ].pos ) );
         double light_intensity = ( diff_sqr > 0 ) ? ( enter_obj->radiance / diff_sqr ) : F3_MAG;
-        V3 c = v_mlf( ld3( enter_obj->color ), light_intensity * intensity );
+        V3 c = v_mlf( obj_color_dev( sc, trans.enter_obj, pos ), light_intensity * intensity );
         acc.x += T.x * c.x; acc.y += T.y * c.y; acc.z += T.z * c.z;
         go = false;
     }
@@ -231,7 +231,7 @@ DEV void shade_hit( const DevScene& sc, const Queues& q, V3 rp, V3 rd, double of
             on_a = 1.0 - 0.5 * sigma_sqr / ( sigma_sqr + 0.33 );
             on_b = 0.45 * sigma_sqr / ( sigma_sqr + 0.09 );
         }
-        enter_color = ld3( enter_obj->color );
+        enter_color = obj_color_dev( sc, trans.enter_obj, pos );
     }
     if( go && exit_obj )   /* :464-470 and the absorption of :656-664, which scales everything this call returns */
     {
@@ -340,9 +340,9 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
 #endif
 /* Kernel parameter convention: every buffer is passed as its own __restrict__ pointer and the DevScene / Queues views
  * are rebuilt inside (scene arrays are then read through the constant address space, see acn_device.h). */
-#define ACN_SCENE_PARAMS  DevScene sc_in, const GNode* __restrict__ p_nodes, const GMat* __restrict__ p_mats, const int32_t* __restrict__ p_elems
-#define ACN_SCENE_ARGS( h ) ( h )->dev, ( h )->d_nodes, ( h )->d_mats, ( h )->d_elems
-#define ACN_SCENE_VIEW    DevScene sc = sc_in; sc.nodes = ( NodeP )p_nodes; sc.mats = ( MatP )p_mats; sc.elems = ( ElemP )p_elems; sc.flags = p_counts + QC_FLAGS;
+#define ACN_SCENE_PARAMS  DevScene sc_in, const GNode* __restrict__ p_nodes, const GMat* __restrict__ p_mats, const int32_t* __restrict__ p_elems, const acn_texture* __restrict__ p_textures
+#define ACN_SCENE_ARGS( h ) ( h )->dev, ( h )->d_nodes, ( h )->d_mats, ( h )->d_elems, ( h )->d_textures
+#define ACN_SCENE_VIEW    DevScene sc = sc_in; sc.nodes = ( NodeP )p_nodes; sc.mats = ( MatP )p_mats; sc.elems = ( ElemP )p_elems; sc.textures = ( TexP )p_textures; sc.flags = p_counts + QC_FLAGS;
 
 /* LDS staging of the node array (kernels whose node reads are per-lane: the CSG machines).  The block copies the
  * GNode array into dynamic shared memory once; per-lane node reads then are ds_read instead of global loads. */
@@ -527,6 +527,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
             direct_samples = ( direct_samples == 0 ) ? 1 : direct_samples;
             V3 light_pos = ld3( light_src->pos );
             double radiance = light_mat->radiance;
+            const V3 light_color = obj_color_dev( sc, light_idx, light_pos );   /* scene.c:552 */
 
             double s = 0;
             uint64_t rvj = lcg_jump_lane( rv, sub );
@@ -560,7 +561,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                         double f = c * ( 2.0 * cyl_hgt / direct_samples );
                         V3 Tc = ldc( t.Tc );
                         h.pos = pos; h.d = out_d; h.limit = a;
-                        h.contrib = mk( Tc.x * ( light_mat->color[ 0 ] * f ), Tc.y * ( light_mat->color[ 1 ] * f ), Tc.z * ( light_mat->color[ 2 ] * f ) );
+                        h.contrib = mk( Tc.x * ( light_color.x * f ), Tc.y * ( light_color.y * f ), Tc.z * ( light_color.z * f ) );
                         h.pixel = t.pixel; h.pad = 0;
                     }
                     else
@@ -572,7 +573,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
             rv = lcg00_jump( rv, 2 * direct_samples );
             s = group_sum< LPT >( s );
             double f = s * ( 2.0 * cyl_hgt / direct_samples );
-            lum.x += light_mat->color[ 0 ] * f; lum.y += light_mat->color[ 1 ] * f; lum.z += light_mat->color[ 2 ] * f;
+            lum.x += light_color.x * f; lum.y += light_color.y * f; lum.z += light_color.z * f;
         }
 
         /* ---- path tracing, scene.c:584-621 ---- */

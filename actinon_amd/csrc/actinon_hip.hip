@@ -27,6 +27,7 @@ struct acn_scene_handle
     GNode*   d_nodes = nullptr;
     GMat*    d_mats = nullptr;
     int32_t* d_elems = nullptr;
+    acn_texture* d_textures = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -225,7 +226,14 @@ static int validate( const acn_flat_scene* sc, int* max_csg )
     for( uint32_t i = 0; i < sc->n_nodes; i++ )
     {
         const acn_node* n = &sc->nodes[ i ];
-        if( n->texture != -1 ) return fail( ACN_ERR_UNSUPPORTED, "texture fields are not supported" );
+        if( n->texture != -1 )
+        {
+            if( n->texture < 0 || ( uint32_t )n->texture >= sc->n_textures || !sc->textures ) return fail( ACN_ERR_ARG, "bad texture index" );
+            const acn_texture* t = &sc->textures[ n->texture ];
+            if( t->kind != ACN_TXM_PLAIN && t->kind != ACN_TXM_CHESS ) return fail( ACN_ERR_ARG, "unknown texture kind" );
+            if( t->kind == ACN_TXM_CHESS && n->type != ACN_PLANE && n->type != ACN_SPHERE && n->type != ACN_DISTANCE )
+                return fail( ACN_ERR_UNSUPPORTED, "object has no projection-function for a chess texture (objects.c:240-245)" );
+        }
         switch( n->type )
         {
             case ACN_PLANE: case ACN_SPHERE: case ACN_SQUAROID: break;
@@ -320,10 +328,13 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
         m.fresnel_reflectivity = a.fresnel_reflectivity; m.chromatic_reflectivity = a.chromatic_reflectivity;
         m.diffuse_reflectivity = a.diffuse_reflectivity; m.sigma = a.sigma;
         memcpy( m.transparency, a.transparency, sizeof( m.transparency ) );
+        m.texture = a.texture; m.pad_ = 0;
     }
     HIP_TRY_H( hipMalloc( &h->d_nodes, sizeof( GNode ) * scene->n_nodes ) );
     HIP_TRY_H( hipMalloc( &h->d_mats, sizeof( GMat ) * scene->n_nodes ) );
     HIP_TRY_H( hipMalloc( &h->d_elems, sizeof( int32_t ) * ( scene->n_elems ? scene->n_elems : 1 ) ) );
+    HIP_TRY_H( hipMalloc( &h->d_textures, sizeof( acn_texture ) * ( scene->n_textures ? scene->n_textures : 1 ) ) );
+    if( scene->n_textures ) HIP_TRY_H( hipMemcpy( h->d_textures, scene->textures, sizeof( acn_texture ) * scene->n_textures, hipMemcpyHostToDevice ) );
     HIP_TRY_H( hipMalloc( &h->d_counters, sizeof( unsigned long long ) * CNT_N ) );
     HIP_TRY_H( hipMemset( h->d_counters, 0, sizeof( unsigned long long ) * CNT_N ) );
     HIP_TRY_H( hipMalloc( &h->q.counts, sizeof( uint32_t ) * QC_N ) );
@@ -334,6 +345,7 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     h->dev.nodes = ( NodeP )h->d_nodes;
     h->dev.mats = ( MatP )h->d_mats;
     h->dev.elems = ( ElemP )h->d_elems;
+    h->dev.textures = ( TexP )h->d_textures;
     h->dev.light_root = scene->light_root;
     h->dev.matter_root = scene->matter_root;
     h->dev.n_nodes = scene->n_nodes;
@@ -395,6 +407,7 @@ extern "C" void acn_scene_free( acn_scene_handle* h )
     if( h->d_nodes ) hipFree( h->d_nodes );
     if( h->d_mats ) hipFree( h->d_mats );
     if( h->d_elems ) hipFree( h->d_elems );
+    if( h->d_textures ) hipFree( h->d_textures );
     if( h->d_counters ) hipFree( h->d_counters );
     for( auto& e : h->events ) { hipEventDestroy( e.a ); hipEventDestroy( e.b ); }
     if( h->ev0 ) hipEventDestroy( h->ev0 );

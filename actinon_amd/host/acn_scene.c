@@ -25,6 +25,8 @@ struct acn_obj
     int    has_env;
     acn_v3 env_pos;
     double env_radius;
+    int    has_tex;          /* prp.texture_field (deep-copied with the properties) */
+    acn_texture tex;
     /* type parameters */
     double prm[ 4 ];
     int sdf_kind;
@@ -191,6 +193,7 @@ static void prp_copy( acn_obj* dst, const acn_obj* src )
     dst->diffuse_reflectivity = src->diffuse_reflectivity; dst->sigma = src->sigma;
     dst->surface_roughness = src->surface_roughness; dst->transparency = src->transparency;
     dst->has_env = src->has_env; dst->env_pos = src->env_pos; dst->env_radius = src->env_radius;
+    dst->has_tex = src->has_tex; dst->tex = src->tex;
 }
 
 /* objects.c:1011-1018 */
@@ -354,6 +357,25 @@ void acn_obj_set_diffuse_reflectivity( acn_obj* o, double v ) { o->diffuse_refle
 void acn_obj_set_sigma( acn_obj* o, double v ) { o->sigma = v; }
 void acn_obj_set_surface_roughness( acn_obj* o, double v ) { o->surface_roughness = v; }
 double acn_obj_radiance( const acn_obj* o ) { return o->radiance; }
+
+void acn_obj_set_texture_field_plain( acn_obj* o, acn_v3 color )
+{
+    memset( &o->tex, 0, sizeof( o->tex ) );
+    o->has_tex = 1; o->tex.kind = ACN_TXM_PLAIN;
+    o->tex.color1[ 0 ] = color.x; o->tex.color1[ 1 ] = color.y; o->tex.color1[ 2 ] = color.z;
+    o->tex.scale = 1.0;
+}
+
+void acn_obj_set_texture_field_chess( acn_obj* o, acn_v3 c1, acn_v3 c2, double scale )
+{
+    memset( &o->tex, 0, sizeof( o->tex ) );
+    o->has_tex = 1; o->tex.kind = ACN_TXM_CHESS;
+    o->tex.color1[ 0 ] = c1.x; o->tex.color1[ 1 ] = c1.y; o->tex.color1[ 2 ] = c1.z;
+    o->tex.color2[ 0 ] = c2.x; o->tex.color2[ 1 ] = c2.y; o->tex.color2[ 2 ] = c2.z;
+    o->tex.scale = scale;
+}
+
+void acn_obj_clear_texture_field( acn_obj* o ) { o->has_tex = 0; }
 
 void acn_obj_set_envelope( acn_obj* o, acn_v3 pos, double radius )
 {
@@ -587,6 +609,7 @@ typedef struct
 {
     acn_node* nodes; uint32_t n_nodes, node_space;
     int32_t*  elems; uint32_t n_elems, elem_space;
+    acn_texture* tex; uint32_t n_tex, tex_space;
 } flat_builder;
 
 static int32_t fb_new_node( flat_builder* b )
@@ -623,6 +646,16 @@ static int32_t fb_add( flat_builder* b, const acn_obj* o )
     n.sdf_kind = o->sdf_kind;
     n.cycles = o->cycles;
     n.texture = -1;
+    if( o->has_tex )
+    {
+        if( b->n_tex == b->tex_space )
+        {
+            b->tex_space = b->tex_space ? b->tex_space * 2 : 8;
+            b->tex = realloc( b->tex, sizeof( acn_texture ) * b->tex_space );
+        }
+        n.texture = ( int32_t )b->n_tex;
+        b->tex[ b->n_tex++ ] = o->tex;
+    }
     n.pos[ 0 ] = o->pos.x; n.pos[ 1 ] = o->pos.y; n.pos[ 2 ] = o->pos.z;
     n.rax[ 0 ] = o->rax.x.x; n.rax[ 1 ] = o->rax.x.y; n.rax[ 2 ] = o->rax.x.z;
     n.rax[ 3 ] = o->rax.y.x; n.rax[ 4 ] = o->rax.y.y; n.rax[ 5 ] = o->rax.y.z;
@@ -674,6 +707,8 @@ int acn_scene_s_flatten( const acn_scene* o, acn_flat_scene* out )
     out->nodes = b.nodes;
     out->elems = b.elems ? b.elems : calloc( 1, sizeof( int32_t ) );
     out->params = o->prm;
+    out->n_textures = b.n_tex;
+    out->textures = b.tex;
     return ACN_OK;
 }
 
@@ -693,5 +728,6 @@ void acn_flat_scene_free( acn_flat_scene* f )
     if( !f ) return;
     free( ( void* )f->nodes );
     free( ( void* )f->elems );
-    f->nodes = NULL; f->elems = NULL; f->n_nodes = f->n_elems = 0;
+    free( ( void* )f->textures );
+    f->nodes = NULL; f->elems = NULL; f->textures = NULL; f->n_nodes = f->n_elems = f->n_textures = 0;
 }

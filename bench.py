@@ -42,6 +42,19 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
+def measured_traffic(workload, world):
+    """HBM bytes per main pass from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 per the gfx950
+    correction + WRITE_SIZE, KB -> bytes), for the same workload on one GPU; None if no such profile exists."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    try:
+        t = json.load(open(path))
+        return t.get(workload, {}).get("hbm_bytes_per_step")
+    except (OSError, ValueError):
+        return None
+
+
 def host_core_share():
     """Host cores this job may use: the cgroup CPU quota if one is set (a 1-GPU box gets a share of the host),
     else the affinity mask."""
@@ -187,7 +200,7 @@ def main():
         elapsed = float(t.item())
 
     # kernel duration of the dominant kernel: HIP events recorded by the library on the launch stream
-    for _ in range(min(3, max(1, args.steps))):
+    for _ in range(min(2, max(1, args.steps))):
         step(True)
     stages = handle.last_stages()
     # one extra, untimed pass through the instrumented kernels for the work counters
@@ -228,9 +241,11 @@ def main():
                        "pixels": n_pix, "path_samples": S, "partition": f"pixel tiles of {adist.TILE}, round-robin over {world} rank(s)",
                        "reduce": "RCCL all_reduce(sum, f64, W*H*3)" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_render", "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
-                         "note": "path is fp64-VALU bound; HBM roofline reported as BASELINE.json asks"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, world),
+                         "kernel": "trace pipeline of one main pass (k_trace_rays + k_shade + k_hard_shadow + k_hard_path + k_finalize)",
+                         "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
+                         "note": "the path is fp64-VALU-issue bound with divergent CSG traversal; the HBM roofline is "
+                                 "reported because BASELINE.json asks for it (DESIGN.md 7)"},
             "stages": stages,
             "work": {"rays_per_step_rank0": counters["trans_rays"] + counters["shadow_rays"],
                      "obj_hit_tests_rank0": counters["obj_hits"],

@@ -69,6 +69,10 @@ void acn_obj_set_chromatic_reflectivity( acn_obj* o, double v );
 void acn_obj_set_diffuse_reflectivity( acn_obj* o, double v );
 void acn_obj_set_sigma( acn_obj* o, double v );
 void acn_obj_set_surface_roughness( acn_obj* o, double v );
+/* obj_set_texture_field (objects.c:450-456) with txm_plain_s / txm_chess_s (textures.c) */
+void acn_obj_set_texture_field_plain( acn_obj* o, acn_v3 color );
+void acn_obj_set_texture_field_chess( acn_obj* o, acn_v3 color1, acn_v3 color2, double scale );
+void acn_obj_clear_texture_field( acn_obj* o );
 int  acn_obj_set_material( acn_obj* o, const char* name );      /* 0 ok, ACN_ERR_ARG unknown preset */
 void acn_obj_set_envelope( acn_obj* o, acn_v3 pos, double radius );   /* objects and compounds */
 int  acn_obj_set_auto_envelope( acn_obj* o );                   /* objects.c:470-476 / compound.c:73-107; runs on the GPU */

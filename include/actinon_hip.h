@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ACN_ABI_VERSION 1
+#define ACN_ABI_VERSION 2
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* Flattened scene.  One acn_node per reference object (obj_*_s, src/objects.c) or compound_s (src/compound.c:36-50).
@@ -61,7 +61,7 @@ typedef struct acn_node
     int32_t  child1;      /* pair: o2 | compound: number of elements | else -1 */
     int32_t  sdf_kind;    /* ACN_DISTANCE: enum acn_sdf_kind */
     int32_t  cycles;      /* ACN_DISTANCE: obj_distance_s.cycles */
-    int32_t  texture;     /* reserved (prp.texture_field); must be -1 */
+    int32_t  texture;     /* prp.texture_field: index into acn_flat_scene.textures, -1 = none */
     int32_t  reserved;
 
     double pos[3];        /* prp.pos */
@@ -81,6 +81,24 @@ typedef struct acn_node
     double transparency[3];
     double pad_;
 } acn_node;
+
+/* Texture fields (src/textures.c): the colour of an object's surface as a function of position, obj_color
+ * src/objects.c:411-422.  ACN_TXM_CHESS uses obj_projection, which only planes (objects.c:514-518), spheres (:602-617)
+ * and distance objects (:893-896) implement; on any other object type it is rejected at upload. */
+enum acn_texture_kind
+{
+    ACN_TXM_PLAIN = 0,    /* txm_plain_s src/textures.c:62-102 : color1 */
+    ACN_TXM_CHESS = 1     /* txm_chess_s src/textures.c:118-148: ( llrint( p.x*scale ) ^ llrint( p.y*scale ) ) & 1 ? color1 : color2 */
+};
+
+typedef struct acn_texture
+{
+    int32_t kind;
+    int32_t reserved;
+    double  color1[3];
+    double  color2[3];
+    double  scale;
+} acn_texture;
 
 /* Render parameters: the scene_s fields the hot path reads (src/scene.c:153-183; defaults :185-213). */
 typedef struct acn_params
@@ -112,6 +130,9 @@ typedef struct acn_flat_scene
     const acn_node* nodes;
     const int32_t*  elems;
     acn_params      params;
+    uint32_t        n_textures;
+    uint32_t        reserved2;
+    const acn_texture* textures;
 } acn_flat_scene;
 
 /* The 64-bit LCG triple the reference takes from beth (bcore_lcg00/01/02_u3; src/vectors.h:45-48,185-189).
@@ -144,7 +165,7 @@ enum acn_status
 {
     ACN_OK              =  0,
     ACN_ERR_ARG         = -1,  /* malformed scene / argument */
-    ACN_ERR_UNSUPPORTED = -2,  /* experimental_level != 0 (src/scene.c:1004-1007), texture field, too-deep CSG */
+    ACN_ERR_UNSUPPORTED = -2,  /* experimental_level != 0 (src/scene.c:1004-1007), projection-less chess texture, too-deep CSG */
     ACN_ERR_NO_FOV      = -3,  /* light object without fov function (src/objects.c:254-258) */
     ACN_ERR_DEVICE      = -4,  /* HIP failure, no GPU */
     ACN_ERR_CANCELLED   = -5

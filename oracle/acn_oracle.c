@@ -19,6 +19,9 @@
 #define M_LOG( x )     log( x )
 #define M_POW( x, y )  pow( x, y )
 #define M_SQRT( x )    sqrt( x )
+#define M_ATAN2( y, x ) atan2( y, x )
+#define M_ASIN( x )    asin( x )
+#define M_LLRINT( x )  llrint( x )
 static double m_frexp_mant( double v ) { int e = 0; return frexp( v, &e ); }
 int acn_oracle_math_mode( void ) { return 1; }
 #else
@@ -30,6 +33,9 @@ int acn_oracle_math_mode( void ) { return 1; }
 #define M_LOG( x )     acn_log( x )
 #define M_POW( x, y )  acn_pow( x, y )
 #define M_SQRT( x )    acn_sqrt( x )
+#define M_ATAN2( y, x ) acn_atan2( y, x )
+#define M_ASIN( x )    acn_asin( x )
+#define M_LLRINT( x )  acn_llrint( x )
 static double m_frexp_mant( double v ) { return acn_frexp_mant( v ); }
 int acn_oracle_math_mode( void ) { return 0; }
 #endif
@@ -644,6 +650,47 @@ static cone_t obj_fov( const acn_node* o, v3 pos )
     }
 }
 
+/* obj_projection: plane objects.c:514-518, sphere :602-617, distance :893-896 (other types have none and are
+ * rejected at validation when they carry a chess texture) */
+static void obj_projection( const acn_node* o, v3 pos, double* px, double* py )
+{
+    if( o->type == ACN_PLANE )
+    {
+        v3 p = v3_sub( pos, v3_ld( o->pos ) );
+        *px = v3_mlv( p, v3_ld( o->rax ) );
+        *py = v3_mlv( p, v3_ld( o->rax + 3 ) );
+    }
+    else if( o->type == ACN_SPHERE )
+    {
+        v3 r = v3_of_length( v3_sub( pos, v3_ld( o->pos ) ), 1.0 );
+        double x = v3_mlv( r, v3_ld( o->rax ) );
+        double y = v3_mlv( r, v3_mlx( v3_ld( o->rax + 6 ), v3_ld( o->rax ) ) );
+        double z = v3_mlv( r, v3_ld( o->rax + 6 ) );
+        double azimuth = M_ATAN2( x, y );
+        z = z >  1.0 ?  1.0 : z;
+        z = z < -1.0 ? -1.0 : z;
+        *px = azimuth;
+        *py = M_ASIN( z );
+    }
+    else
+    {
+        *px = 0; *py = 0;
+    }
+}
+
+/* obj_color objects.c:411-422 with txm_plain_s_clr / txm_chess_s_clr textures.c:99-102, 142-148 */
+static v3 obj_color( const acn_flat_scene* sc, const acn_node* o, v3 pos )
+{
+    if( o->texture < 0 ) return v3_ld( o->color );
+    const acn_texture* t = &sc->textures[ o->texture ];
+    if( t->kind == ACN_TXM_PLAIN ) return v3_ld( t->color1 );
+    double px, py;
+    obj_projection( o, pos, &px, &py );
+    int64_t x = M_LLRINT( px * t->scale );
+    int64_t y = M_LLRINT( py * t->scale );
+    return ( ( x ^ y ) & 1 ) ? v3_ld( t->color1 ) : v3_ld( t->color2 );
+}
+
 /* ---- src/compound.c:215-299 -------------------------------------------------------------------------------------- */
 static double compound_ray_hit( ctx_t* c, int cmp, const ray_t* ray, v3* p_nor, int* hit_obj )
 {
@@ -792,7 +839,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
     {
         double diff_sqr = v3_diff_sqr( pos, v3_ld( enter_obj->pos ) );
         double light_intensity = ( diff_sqr > 0 ) ? ( enter_obj->radiance / diff_sqr ) : F3_MAG;
-        return v3_mlf( v3_ld( enter_obj->color ), light_intensity * intensity );
+        return v3_mlf( obj_color( c->sc, enter_obj, pos ), light_intensity * intensity );
     }
 
     double trans_refractive_index = 1.0;
@@ -829,7 +876,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
 
     /* obj_color( trans->enter_obj, pos ) (objects.c:411-422; texture fields unsupported). The reference
      * dereferences a NULL enter_obj here when trace_min_intensity == 0; the restatement uses white. */
-    v3 enter_color = enter_obj ? v3_ld( enter_obj->color ) : V( 1, 1, 1 );
+    v3 enter_color = enter_obj ? obj_color( c->sc, enter_obj, pos ) : V( 1, 1, 1 );
 
     /* fresnel reflection :473-495 */
     if( fresnel_reflectivity > 0 && intensity >= scene->trace_min_intensity )
@@ -901,7 +948,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
             cone_t fov_to_src = obj_fov( light_src, pos );
             m3 src_con = m3_transposed( m3_con_z( fov_to_src.ray.d ) );
             double cyl_hgt = 1 - fov_to_src.cos_rs; /* areal_coverage vectors.h:362 */
-            v3 color = v3_ld( light_src->color );
+            v3 color = obj_color( c->sc, light_src, v3_ld( light_src->pos ) );
             uint64_t direct_samples = ( uint64_t )( scene->direct_samples * diffuse_intensity );
             direct_samples = ( direct_samples == 0 ) ? 1 : direct_samples;
 
@@ -1069,7 +1116,13 @@ static int validate( const acn_flat_scene* sc )
     for( uint32_t i = 0; i < sc->n_nodes; i++ )
     {
         const acn_node* n = &sc->nodes[ i ];
-        if( n->texture != -1 ) return ACN_ERR_UNSUPPORTED;
+        if( n->texture != -1 )
+        {
+            if( n->texture < 0 || ( uint32_t )n->texture >= sc->n_textures || !sc->textures ) return ACN_ERR_ARG;
+            const acn_texture* t = &sc->textures[ n->texture ];
+            if( t->kind != ACN_TXM_PLAIN && t->kind != ACN_TXM_CHESS ) return ACN_ERR_ARG;
+            if( t->kind == ACN_TXM_CHESS && n->type != ACN_PLANE && n->type != ACN_SPHERE && n->type != ACN_DISTANCE ) return ACN_ERR_UNSUPPORTED;
+        }
         switch( n->type )
         {
             case ACN_PLANE: case ACN_SPHERE: case ACN_SQUAROID: case ACN_DISTANCE: break;

@@ -53,6 +53,15 @@ def test_validation_mirrors_reference_aborts():
     with pytest.raises(A.AcnError) as e:
         A.Handle(sc.flatten())
     assert e.value.status == abi.ACN_ERR_NO_FOV
+    # chess texture on an object type without projection function (objects.c:240-245 aborts at shading time)
+    sc = A.Scene()
+    el = host.acn_obj_squaroid_s_create_ellipsoid(1, 1, 1)
+    host.acn_obj_set_texture_field_chess(el, A.v3(1, 0, 0), A.v3(0, 0, 1), 1.0)
+    sc.push(el)
+    host.acn_obj_discard(el)
+    with pytest.raises(A.AcnError) as e:
+        A.Handle(sc.flatten())
+    assert e.value.status == abi.ACN_ERR_UNSUPPORTED
     # corrupt flat scene
     flat = A.Scene.build("primitives").flatten()
     flat.c.abi_version = 99
