@@ -9,18 +9,23 @@ WALK_WAVES  ?= 4
 EXTRA_DEFS ?=
 HIPFLAGS := $(EXTRA_DEFS) -DACN_SHADE_WAVES=$(SHADE_WAVES) -DACN_WALK_WAVES=$(WALK_WAVES) -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Iinclude -Iactinon_amd/csrc -std=c++17 -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
 
-all: hip host oracle
+all: hip host oracle cli
 
 hip: $(LIBDIR)/libactinon_hip.so
 host: $(LIBDIR)/libactinon_host.so
 oracle: oracle/libacn_oracle.so oracle/libacn_oracle_libm.so
+cli: actinon_amd/bin/actinon_hip
 
 $(LIBDIR)/libactinon_hip.so: actinon_amd/csrc/actinon_hip.hip $(wildcard actinon_amd/csrc/*.h) include/actinon_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ actinon_amd/csrc/actinon_hip.hip
 
-$(LIBDIR)/libactinon_host.so: actinon_amd/host/acn_scene.c actinon_amd/host/acn_driver.c actinon_amd/host/acn_scenes.c include/acn_scene.h include/actinon_hip.h $(LIBDIR)/libactinon_hip.so
-	$(CC) $(CFLAGS) -shared -o $@ actinon_amd/host/acn_scene.c actinon_amd/host/acn_driver.c actinon_amd/host/acn_scenes.c -L$(LIBDIR) -lactinon_hip -lm -Wl,-rpath,'$$ORIGIN'
+$(LIBDIR)/libactinon_host.so: actinon_amd/host/acn_scene.c actinon_amd/host/acn_driver.c actinon_amd/host/acn_scenes.c actinon_amd/host/acn_interp.c include/acn_scene.h include/acn_interp.h include/actinon_hip.h $(LIBDIR)/libactinon_hip.so
+	$(CC) $(CFLAGS) -shared -o $@ actinon_amd/host/acn_scene.c actinon_amd/host/acn_driver.c actinon_amd/host/acn_scenes.c actinon_amd/host/acn_interp.c -L$(LIBDIR) -lactinon_hip -lm -Wl,-rpath,'$$ORIGIN'
+
+actinon_amd/bin/actinon_hip: tools/actinon_hip.c include/acn_interp.h $(LIBDIR)/libactinon_host.so
+	@mkdir -p actinon_amd/bin
+	$(CC) $(CFLAGS) -o $@ tools/actinon_hip.c -L$(LIBDIR) -lactinon_host -lactinon_hip -lm -Wl,-rpath,'$$ORIGIN/../lib'
 
 oracle/libacn_oracle.so: oracle/acn_oracle.c oracle/acn_oracle.h actinon_amd/csrc/acn_detmath.h include/actinon_hip.h
 	$(CC) $(CFLAGS) -march=native -Ioracle -shared -o $@ oracle/acn_oracle.c -lm -lpthread
@@ -29,6 +34,6 @@ oracle/libacn_oracle_libm.so: oracle/acn_oracle.c oracle/acn_oracle.h include/ac
 	$(CC) $(CFLAGS) -march=native -DACN_ORACLE_LIBM -Ioracle -shared -o $@ oracle/acn_oracle.c -lm -lpthread
 
 clean:
-	rm -f $(LIBDIR)/*.so oracle/*.so
+	rm -f $(LIBDIR)/*.so oracle/*.so actinon_amd/bin/actinon_hip
 
-.PHONY: all hip host oracle clean
+.PHONY: all hip host oracle cli clean

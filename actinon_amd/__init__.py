@@ -5,7 +5,7 @@ and libactinon_host.so (plain-C scene assembly + render driver, include/acn_scen
 plumbing over them for tests and benchmarks; importing it fails if the libraries are not built."""
 from . import abi
 from ._lib import AcnError, check, hip, host
-from .scene import (Flat, Handle, Scene, cps_from_cl, detmath_eval, device_count, main_pass_positions, v3)
+from .scene import (Flat, Handle, Scene, cps_from_cl, detmath_eval, device_count, main_pass_positions, run_script, v3)
 
-__all__ = ["abi", "AcnError", "check", "hip", "host", "Flat", "Handle", "Scene", "cps_from_cl", "detmath_eval",
+__all__ = ["abi", "AcnError", "check", "hip", "host", "Flat", "Handle", "Scene", "cps_from_cl", "detmath_eval", "run_script",
            "device_count", "main_pass_positions", "v3"]

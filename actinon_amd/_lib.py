@@ -42,7 +42,11 @@ HOST_SYMBOLS = ["acn_rotx", "acn_roty", "acn_rotz", "acn_obj_plane_s_create", "a
                 "acn_scene_s_discard", "acn_scene_s_clear", "acn_scene_s_push", "acn_scene_s_objects",
                 "acn_scene_s_flatten", "acn_flat_scene_free", "acn_obj_flatten", "acn_lum_machine_s_run",
                 "acn_scene_s_create_image_file", "acn_write_pnm", "acn_cps_from_cl", "acn_scene_primitives",
-                "acn_scene_wine_glass", "acn_scene_diamond", "acn_scene_many_spheres"]
+                "acn_scene_wine_glass", "acn_scene_diamond", "acn_scene_many_spheres", "acn_obj_get_pos",
+                "acn_obj_sphere_s_get_radius", "acn_obj_get_field", "acn_obj_set_field", "acn_set_envelope_estimator"]
+# symbols declared by include/acn_interp.h
+INTERP_SYMBOLS = ["acn_interpret_file", "acn_interpret_string", "acn_interp_last_error", "acn_scene_from_script",
+                  "acn_scene_s_clone"]
 
 P = C.POINTER
 vp = C.c_void_p
@@ -142,6 +146,30 @@ host.acn_scene_s_push.restype = C.c_size_t
 host.acn_scene_s_objects.argtypes = [vp]
 host.acn_scene_s_objects.restype = C.c_size_t
 host.acn_scene_s_flatten.argtypes = [vp, P(abi.FlatScene)]
+host.acn_obj_get_pos.argtypes = [vp, P(C.c_double)]
+host.acn_obj_get_pos.restype = None
+host.acn_obj_sphere_s_get_radius.argtypes = [vp]
+host.acn_obj_sphere_s_get_radius.restype = C.c_double
+host.acn_obj_get_field.argtypes = [vp, C.c_char_p, P(C.c_double)]
+host.acn_obj_set_field.argtypes = [vp, C.c_char_p, C.c_double]
+host.acn_set_envelope_estimator.argtypes = [vp]
+host.acn_set_envelope_estimator.restype = None
+CREATE_IMAGE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_char_p)
+
+
+class InterpOpts(C.Structure):
+    _fields_ = [("on_create_image", CREATE_IMAGE_FN), ("ctx", vp), ("auto_envelope", C.c_int), ("readonly_fs", C.c_int),
+                ("argc", C.c_int),
+                ("argv", P(C.c_char_p))]
+
+
+host.acn_interpret_file.argtypes = [C.c_char_p, P(InterpOpts)]
+host.acn_interpret_string.argtypes = [C.c_char_p, C.c_char_p, P(InterpOpts)]
+host.acn_interp_last_error.restype = C.c_char_p
+host.acn_scene_from_script.argtypes = [C.c_char_p, C.c_int]
+host.acn_scene_from_script.restype = vp
+host.acn_scene_s_clone.argtypes = [vp]
+host.acn_scene_s_clone.restype = vp
 host.acn_flat_scene_free.argtypes = [P(abi.FlatScene)]
 host.acn_flat_scene_free.restype = None
 host.acn_obj_flatten.argtypes = [vp, P(abi.FlatScene), P(C.c_int32)]

@@ -416,8 +416,14 @@ DEV void trace_rays_body( const DevScene& sc, const SCL& scl, const Queues& q, c
     wave_add_counters( counters, cnt );
 }
 
+#ifndef ACN_TRACE_WAVES
+#define ACN_TRACE_WAVES ACN_WALK_WAVES
+#endif
+#ifndef ACN_HPATH_WAVES
+#define ACN_HPATH_WAVES ACN_WALK_WAVES
+#endif
 template< bool PRIMARY, bool COUNT, bool LDS >
-__global__ __launch_bounds__( 256, ACN_WALK_WAVES )
+__global__ __launch_bounds__( 256, ACN_TRACE_WAVES )
 void k_trace_rays( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __restrict__ rays_in,
                    const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n,
                    unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
@@ -671,7 +677,7 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
 
 /* the path rays k_shade could not finish inline: full transition hit; hits join the next level's HitRec queue */
 template< bool COUNT, bool LDS >
-__global__ __launch_bounds__( 256, ACN_WALK_WAVES )
+__global__ __launch_bounds__( 256, ACN_HPATH_WAVES )
 void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t n, HitRec* __restrict__ p_children, uint32_t child_cap,
                   uint32_t* __restrict__ p_counts, unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {

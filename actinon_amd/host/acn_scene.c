@@ -357,6 +357,37 @@ void acn_obj_set_diffuse_reflectivity( acn_obj* o, double v ) { o->diffuse_refle
 void acn_obj_set_sigma( acn_obj* o, double v ) { o->sigma = v; }
 void acn_obj_set_surface_roughness( acn_obj* o, double v ) { o->surface_roughness = v; }
 double acn_obj_radiance( const acn_obj* o ) { return o->radiance; }
+void   acn_obj_get_pos( const acn_obj* o, double* pos3 ) { pos3[ 0 ] = o->pos.x; pos3[ 1 ] = o->pos.y; pos3[ 2 ] = o->pos.z; }
+double acn_obj_sphere_s_get_radius( const acn_obj* o ) { return o->type == ACN_SPHERE ? o->prm[ 0 ] : 0; }   /* objects.c:601-604 */
+
+/* The reflected leaf members a script can reach as `obj.name` (objects.c:571-577 sphere, 685-694 squaroid) */
+static double* obj_field( const acn_obj* o, const char* name )
+{
+    acn_obj* m = ( acn_obj* )o;
+    if( o->type == ACN_SPHERE && !strcmp( name, "radius" ) ) return &m->prm[ 0 ];
+    if( o->type == ACN_SQUAROID && name[ 0 ] && !name[ 1 ] )
+    {
+        if( name[ 0 ] == 'a' ) return &m->prm[ 0 ];
+        if( name[ 0 ] == 'b' ) return &m->prm[ 1 ];
+        if( name[ 0 ] == 'c' ) return &m->prm[ 2 ];
+        if( name[ 0 ] == 'r' ) return &m->prm[ 3 ];
+    }
+    return NULL;
+}
+int acn_obj_get_field( const acn_obj* o, const char* name, double* value )
+{
+    double* p = obj_field( o, name );
+    if( !p ) return 0;
+    *value = *p;
+    return 1;
+}
+int acn_obj_set_field( acn_obj* o, const char* name, double value )
+{
+    double* p = obj_field( o, name );
+    if( !p ) return 0;
+    *p = value;
+    return 1;
+}
 
 void acn_obj_set_texture_field_plain( acn_obj* o, acn_v3 color )
 {
@@ -511,6 +542,9 @@ void acn_compound_s_set_sphere_envelopes( acn_obj* c, double factor )
 }
 
 /* ---- auto envelope: objects.c:470-476 (1000 samples, seed 123, factor 1.1), compound.c:73-107 ---- */
+static acn_envelope_estimator_fn envelope_estimator_g = NULL;
+void acn_set_envelope_estimator( acn_envelope_estimator_fn fn ) { envelope_estimator_g = fn; }
+
 int acn_obj_set_auto_envelope( acn_obj* o )
 {
     if( o->type != ACN_COMPOUND )
@@ -519,11 +553,15 @@ int acn_obj_set_auto_envelope( acn_obj* o )
         int32_t node = -1;
         int st = acn_obj_flatten( o, &f, &node );
         if( st != ACN_OK ) return st;
-        acn_scene_handle* h = NULL;
-        st = acn_scene_upload( &f, 0, &h );
         double env[ 4 ] = { 0, 0, 0, 0 };
-        if( st == ACN_OK ) st = acn_estimate_envelope( h, node, 1000, 123, 1.1, env );
-        if( h ) acn_scene_free( h );
+        if( envelope_estimator_g ) st = envelope_estimator_g( &f, node, 1000, 123, 1.1, env );
+        else
+        {
+            acn_scene_handle* h = NULL;
+            st = acn_scene_upload( &f, 0, &h );
+            if( st == ACN_OK ) st = acn_estimate_envelope( h, node, 1000, 123, 1.1, env );
+            if( h ) acn_scene_free( h );
+        }
         acn_flat_scene_free( &f );
         if( st != ACN_OK ) return st;
         acn_obj_set_envelope( o, V( env[ 0 ], env[ 1 ], env[ 2 ] ), env[ 3 ] );

@@ -47,6 +47,48 @@ class Flat:
     def nodes_bytes(self):
         return C.string_at(self.c.nodes, C.sizeof(abi.Node) * self.c.n_nodes)
 
+    def save(self, path, driver=(0.1, 10, 1)):
+        """Writes the flat scene as a compressed .npz (nodes / elems / params / textures as raw ABI bytes)."""
+        tex = C.string_at(self.c.textures, C.sizeof(abi.Texture) * self.c.n_textures) if self.c.n_textures else b""
+        np.savez_compressed(
+            path, abi_version=self.c.abi_version, nodes=np.frombuffer(self.nodes_bytes(), dtype=np.uint8),
+            elems=np.array(self.c.elems[:self.c.n_elems], dtype=np.int32),
+            params=np.frombuffer(C.string_at(C.addressof(self.c.params), C.sizeof(abi.Params)), dtype=np.uint8),
+            textures=np.frombuffer(tex, dtype=np.uint8),
+            roots=np.array([self.c.light_root, self.c.matter_root], dtype=np.int32), driver=np.array(driver, dtype=np.float64))
+
+    @classmethod
+    def load(cls, path, **overrides):
+        """Inverse of save(); arrays are owned by Python.  overrides set acn_params fields."""
+        z = np.load(path)
+        if int(z["abi_version"]) != abi.ACN_ABI_VERSION:
+            raise AcnError(abi.ACN_ERR_ARG, f"{path}: flat scene of ABI {int(z['abi_version'])}, library is {abi.ACN_ABI_VERSION}")
+        f = cls()
+        nb = z["nodes"].tobytes()
+        n = len(nb) // C.sizeof(abi.Node)
+        f._nodes = (abi.Node * max(1, n)).from_buffer_copy(nb.ljust(C.sizeof(abi.Node), b"\0"))
+        el = z["elems"].astype(np.int32)
+        f._elems = (C.c_int32 * max(1, len(el)))(*[int(v) for v in el])
+        tb = z["textures"].tobytes() if "textures" in z.files else b""
+        nt = len(tb) // C.sizeof(abi.Texture)
+        f._tex = (abi.Texture * max(1, nt)).from_buffer_copy(tb.ljust(C.sizeof(abi.Texture), b"\0"))
+        f.c.abi_version = abi.ACN_ABI_VERSION
+        f.c.n_nodes, f.c.n_elems, f.c.n_textures = n, len(el), nt
+        f.c.light_root, f.c.matter_root = int(z["roots"][0]), int(z["roots"][1])
+        f.c.nodes = C.cast(f._nodes, C.POINTER(abi.Node))
+        f.c.elems = C.cast(f._elems, C.POINTER(C.c_int32))
+        f.c.textures = C.cast(f._tex, C.POINTER(abi.Texture))
+        C.memmove(C.addressof(f.c.params), z["params"].tobytes(), C.sizeof(abi.Params))
+        f.driver = tuple(float(v) for v in z["driver"]) if "driver" in z.files else (0.1, 10, 1)
+        for k, v in overrides.items():
+            cur = getattr(f.c.params, k)
+            if hasattr(cur, "__len__"):
+                for i in range(len(cur)):
+                    cur[i] = float(v[i])
+            else:
+                setattr(f.c.params, k, v)
+        return f
+
 
 class Scene:
     """Wraps an acn_scene* (scene_s counterpart)."""
@@ -81,6 +123,19 @@ class Scene:
         sc.set(**overrides)
         return sc
 
+    AUTOENV_GPU, AUTOENV_SKIP = 0, 1
+
+    @classmethod
+    def from_script(cls, path, auto_envelope=0, **overrides):
+        """Interprets an .acn script (include/acn_interp.h) without rendering; returns the scene as it was at the
+        script's first create_image call."""
+        ptr = host.acn_scene_from_script(str(path).encode(), auto_envelope)
+        if not ptr:
+            raise AcnError(abi.ACN_ERR_ARG, host.acn_interp_last_error().decode())
+        sc = cls(ptr)
+        sc.set(**overrides)
+        return sc
+
     def set(self, **kw):
         for k, v in kw.items():
             if hasattr(self.s.prm, k):
@@ -111,13 +166,48 @@ class Scene:
 
     def flatten(self):
         f = Flat()
-        check(host.acn_scene_s_flatten(self.ptr, C.byref(f.c)), "acn_scene_s_flatten")
+        check(host.acn_scene_s_flatten(self.ptr or self._borrowed, C.byref(f.c)), "acn_scene_s_flatten")
         f._owned = True
         return f
 
     def create_image_file(self, path, overwrite=True):
         C.c_int.in_dll(host, "acn_scene_s_overwrite_output_files_g").value = 1 if overwrite else 0
         check(host.acn_scene_s_create_image_file(self.ptr, path.encode()), "acn_scene_s_create_image_file")
+
+
+def run_script(path, on_create_image=None, auto_envelope=0, readonly_fs=False, args=(), overwrite=True):
+    """Interprets an .acn script (acn_interpret_file).  on_create_image( scene: Scene, file: str ) -> None replaces
+    the render driver for `scene.create_image( file )`; None renders on the GPU and writes the PNM like the
+    reference's actinon binary does."""
+    from ._lib import InterpOpts, CREATE_IMAGE_FN
+    C.c_int.in_dll(host, "acn_scene_s_overwrite_output_files_g").value = 1 if overwrite else 0
+    raised = []
+
+    def hook(ctx, scene_ptr, file):
+        try:
+            view = Scene.__new__(Scene)
+            view.ptr = None                      # borrowed: the interpreter owns the scene
+            view.s = C.cast(scene_ptr, C.POINTER(abi.SceneStruct)).contents
+            view._borrowed = scene_ptr
+            on_create_image(view, file.decode())
+            return abi.ACN_OK
+        except Exception as ex:                  # noqa: BLE001 - surfaced after the C call returns
+            raised.append(ex)
+            return abi.ACN_ERR_ARG
+
+    opts = InterpOpts()
+    cb = CREATE_IMAGE_FN(hook) if on_create_image else CREATE_IMAGE_FN()
+    opts.on_create_image = cb
+    opts.auto_envelope = auto_envelope
+    opts.readonly_fs = 1 if readonly_fs else 0
+    argv = (C.c_char_p * max(1, len(args)))(*[a.encode() for a in args])
+    opts.argc = len(args)
+    opts.argv = argv
+    st = host.acn_interpret_file(str(path).encode(), C.byref(opts))
+    if raised:
+        raise raised[0]
+    if st != abi.ACN_OK:
+        raise AcnError(st, host.acn_interp_last_error().decode())
 
 
 class Handle:

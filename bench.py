@@ -37,6 +37,10 @@ WORKLOADS = {
     "c4": ("diamond", dict(image_width=1920, image_height=1080, path_samples=512, direct_samples=50)),
     "c3": ("many_spheres:5:0", dict(image_width=1920, image_height=1080, path_samples=256, direct_samples=20)),
     "smoke": ("wine_glass", dict(image_width=160, image_height=90, path_samples=16, direct_samples=50)),
+    # BASELINE.json configs[4]: the script's own settings (600x800, path 30 / direct 30); the scene comes from the
+    # flattened fixture our interpreter produced from hanging_lamp.acn (tests/golden/make_scene_fixtures.py)
+    "c5": ("fixture:hanging_lamp", dict()),
+    "paraffin_lamp": ("fixture:paraffin_lamp", dict()),
 }
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
@@ -140,8 +144,11 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
 
     builder, ov = WORKLOADS[args.workload]
-    scene = A.Scene.build(builder, **ov)
-    flat = scene.flatten()
+    if builder.startswith("fixture:"):
+        flat = A.Flat.load(os.path.join(ROOT, "tests", "golden", "scenes", builder.split(":")[1] + ".npz"), **ov)
+    else:
+        scene = A.Scene.build(builder, **ov)
+        flat = scene.flatten()
     W, H, S = int(flat.params.image_width), int(flat.params.image_height), int(flat.params.path_samples)
     n_pix = W * H
     handle = A.Handle(flat, device=local_rank)

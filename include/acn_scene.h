@@ -76,7 +76,18 @@ void acn_obj_clear_texture_field( acn_obj* o );
 int  acn_obj_set_material( acn_obj* o, const char* name );      /* 0 ok, ACN_ERR_ARG unknown preset */
 void acn_obj_set_envelope( acn_obj* o, acn_v3 pos, double radius );   /* objects and compounds */
 int  acn_obj_set_auto_envelope( acn_obj* o );                   /* objects.c:470-476 / compound.c:73-107; runs on the GPU */
+/* Test seam: replaces the GPU estimator behind acn_obj_set_auto_envelope (same arguments as acn_estimate_envelope,
+ * scene given flat instead of resident).  The fixture generator under tests/golden/ plugs the oracle's estimator
+ * in where no GPU exists; product code never sets it.  NULL restores the GPU estimator. */
+typedef int ( *acn_envelope_estimator_fn )( const acn_flat_scene* scene, int32_t node, uint64_t samples, uint32_t rseed,
+                                            double radius_factor, double* pos3_radius );
+void acn_set_envelope_estimator( acn_envelope_estimator_fn fn );
 double acn_obj_radiance( const acn_obj* o );
+void   acn_obj_get_pos( const acn_obj* o, double* pos3 );              /* prp.pos */
+double acn_obj_sphere_s_get_radius( const acn_obj* o );                /* 0 when o is no sphere */
+/* members reachable from scripts as `obj.name`: sphere "radius"; squaroid "a" "b" "c" "r". Return 1 if present. */
+int    acn_obj_get_field( const acn_obj* o, const char* name, double* value );
+int    acn_obj_set_field( acn_obj* o, const char* name, double value );
 int  acn_obj_get_envelope( const acn_obj* o, double* pos3_radius ); /* 1 if present */
 
 /* ---- compound_s ---- */
@@ -118,8 +129,11 @@ int  acn_obj_flatten( const acn_obj* o, acn_flat_scene* out, int32_t* node_of_ob
 typedef struct acn_lum { double pos_x, pos_y; double clr[3]; double weight; } acn_lum;
 int acn_lum_machine_s_run( const acn_scene* scene, acn_lum* lum_arr, size_t n );
 
-extern int acn_scene_s_overwrite_output_files_g;    /* scene.h:35 */
-/* Render driver: main pass + gradient cycles, writes `file` (PNM P6) after every pass. Returns acn_status. */
+extern int acn_scene_s_overwrite_output_files_g;    /* scene.h:35  (actinon -f) */
+extern int acn_scene_s_automatic_recover_g;         /* scene.h:36  (actinon -r): resume from `<file>.tmp.lum_image` */
+/* Render driver: main pass + gradient cycles, writes `file` (PNM P6) after every pass. Returns acn_status.
+ * SIGINT during a gradient cycle stops softly: the accumulated image goes to `<file>.tmp.lum_image` and the call
+ * returns ACN_ERR_CANCELLED; a later call with acn_scene_s_automatic_recover_g resumes at that cycle. */
 int acn_scene_s_create_image_file( acn_scene* o, const char* file );
 /* image_cps_s_write_pnm on an RGB float image already gamma-saturated (values in [0,1]) */
 int acn_write_pnm( const char* file, const double* rgb, size_t w, size_t h );

@@ -19,7 +19,9 @@ REF = "/root/reference/image"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_image_blocks.json")
 BLOCK = 16
 IMAGES = {"primitives": "primitives.acn.png", "wine_glass": "wine_glass.acn.png", "diamond": "diamond.acn.png",
-          "many_spheres": "many_spheres.acn.png"}
+          "many_spheres": "many_spheres.acn.png", "pyramid": "pyramid.acn.png", "ruby_heart": "ruby_heart.acn.png",
+          "caustic_of_caustic": "caustic_of_caustic.acn.png", "paraffin_lamp": "paraffin_lamp.acn.png",
+          "paraffin_lamp_on_ledge": "paraffin_lamp_on_ledge.acn.png", "hanging_lamp": "hanging_lamp_acn.png"}
 
 
 def block_means(img, b):
