@@ -158,11 +158,11 @@ template<> struct Cnt< false >
 
 /* the two read-only scene arrays, passed BY VALUE into the non-inlined machines (global address space, so the
  * scene struct is never forced into scratch) */
-template< class NP > struct SceneRefT { NP nodes; ElemP elems; uint32_t* flags; };
+template< class NP > struct SceneRefT { NP nodes; ElemP elems; uint32_t* flags; uint32_t n_elems; };
 #define ACN_FLAG_TASK_OVERFLOW  1u
 #define ACN_FLAG_CHILD_OVERFLOW 2u
 #define ACN_FLAG_STACK_OVERFLOW 4u   /* CSG / compound / ray stack exhausted: the result would be wrong, the call fails */
-template< class NP > __device__ __forceinline__ SceneRefT< NP > sref( const DevSceneT< NP >& sc ) { SceneRefT< NP > r; r.nodes = sc.nodes; r.elems = sc.elems; r.flags = sc.flags; return r; }
+template< class NP > __device__ __forceinline__ SceneRefT< NP > sref( const DevSceneT< NP >& sc ) { SceneRefT< NP > r; r.nodes = sc.nodes; r.elems = sc.elems; r.flags = sc.flags; r.n_elems = sc.n_elems; return r; }
 
 /* ---- vectors.h ---- */
 DEV V3 mk( double x, double y, double z ) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
@@ -829,10 +829,11 @@ DEVN double compound_ray_hit_dev( SR sc, int cmp, V3 rp, V3 rd, bool want_nor, V
     int st_i[ ACN_CMP_MAX_DEPTH ], st_end[ ACN_CMP_MAX_DEPTH ];
     int sp = 0;
     double min_a = F3_INF;
+    const int order = limit >= 0 ? ( int )sc.n_elems : 0;   /* any-hit queries walk the cost-ordered copy of elems */
     {
         auto o = &sc.nodes[ cmp ];
         if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) return F3_INF;
-        st_i[ 0 ] = o->child0; st_end[ 0 ] = o->child0 + o->child1; sp = 1;
+        st_i[ 0 ] = o->child0 + order; st_end[ 0 ] = o->child0 + order + o->child1; sp = 1;
     }
     while( sp > 0 )
     {
@@ -843,7 +844,7 @@ DEVN double compound_ray_hit_dev( SR sc, int cmp, V3 rp, V3 rd, bool want_nor, V
         {
             if( node_has_env( e ) && !env_ray_hits( e, rp, rd ) ) continue;
             if( sp >= ACN_CMP_MAX_DEPTH ) { atomicOr( sc.flags, ACN_FLAG_STACK_OVERFLOW ); continue; }
-            st_i[ sp ] = e->child0; st_end[ sp ] = e->child0 + e->child1; sp++;
+            st_i[ sp ] = e->child0 + order; st_end[ sp ] = e->child0 + order + e->child1; sp++;
             continue;
         }
         V3 nor;
@@ -915,7 +916,7 @@ DEV bool root_occluded( const SC& sc, int cmp, V3 rp, V3 rd, double limit, CT* c
 {
     auto o = &sc.nodes[ cmp ];
     if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) return false;
-    int first = o->child0, count = o->child1;
+    int first = o->child0 + ( int )sc.n_elems, count = o->child1;   /* the cost-ordered copy: cheap elements first */
     for( int i = 0; i < count; i++ )
     {
         int element = __builtin_amdgcn_readfirstlane( sc.elems[ first + i ] );

@@ -6,6 +6,8 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <functional>
+#include <algorithm>
 
 #include "acn_pipeline.h"
 
@@ -332,7 +334,40 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     }
     HIP_TRY_H( hipMalloc( &h->d_nodes, sizeof( GNode ) * scene->n_nodes ) );
     HIP_TRY_H( hipMalloc( &h->d_mats, sizeof( GMat ) * scene->n_nodes ) );
-    HIP_TRY_H( hipMalloc( &h->d_elems, sizeof( int32_t ) * ( scene->n_elems ? scene->n_elems : 1 ) ) );
+    /* elems[ 0 .. n ) as given; elems[ n .. 2n ) the same slices with each compound's elements ordered by estimated
+     * test cost (any-hit occlusion queries are an OR over the elements, so their order is free; closest-hit queries
+     * keep the given order because ties go to the first element, compound.c:225-243) */
+    std::vector< int32_t > elems2( 2 * ( size_t )scene->n_elems + 1, 0 );
+    {
+        std::vector< double > cost( scene->n_nodes, -1.0 );
+        std::function< double( int32_t ) > node_cost = [ & ]( int32_t i ) -> double
+        {
+            if( cost[ i ] >= 0 ) return cost[ i ];
+            const acn_node& a = scene->nodes[ i ];
+            double c = 1;
+            switch( a.type )
+            {
+                case ACN_PLANE: c = 0.5; break;
+                case ACN_SPHERE: c = 1; break;
+                case ACN_SQUAROID: c = 1.5; break;
+                case ACN_DISTANCE: c = 60; break;            /* sphere tracing, up to `cycles` evaluations */
+                case ACN_NEG: case ACN_SCALE: c = 1 + node_cost( a.child0 ); break;
+                case ACN_PAIR_INSIDE: case ACN_PAIR_OUTSIDE: c = 2 + 1.5 * ( node_cost( a.child0 ) + node_cost( a.child1 ) ); break;
+                case ACN_COMPOUND: c = 1; for( int32_t k = 0; k < a.child1; k++ ) c += node_cost( scene->elems[ a.child0 + k ] ); break;
+                default: break;
+            }
+            return cost[ i ] = c;
+        };
+        for( uint32_t k = 0; k < scene->n_elems; k++ ) elems2[ k ] = elems2[ scene->n_elems + k ] = scene->elems[ k ];
+        for( uint32_t i = 0; i < scene->n_nodes; i++ )
+        {
+            const acn_node& a = scene->nodes[ i ];
+            if( a.type != ACN_COMPOUND || a.child1 < 2 ) continue;
+            int32_t* first = elems2.data() + scene->n_elems + a.child0;
+            std::stable_sort( first, first + a.child1, [ & ]( int32_t x, int32_t y ) { return node_cost( x ) < node_cost( y ); } );
+        }
+    }
+    HIP_TRY_H( hipMalloc( &h->d_elems, sizeof( int32_t ) * elems2.size() ) );
     HIP_TRY_H( hipMalloc( &h->d_textures, sizeof( acn_texture ) * ( scene->n_textures ? scene->n_textures : 1 ) ) );
     if( scene->n_textures ) HIP_TRY_H( hipMemcpy( h->d_textures, scene->textures, sizeof( acn_texture ) * scene->n_textures, hipMemcpyHostToDevice ) );
     HIP_TRY_H( hipMalloc( &h->d_counters, sizeof( unsigned long long ) * CNT_N ) );
@@ -341,7 +376,7 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     HIP_TRY_H( hipHostMalloc( &h->h_counts, sizeof( uint32_t ) * QC_N ) );
     HIP_TRY_H( hipMemcpy( h->d_nodes, nodes.data(), sizeof( GNode ) * scene->n_nodes, hipMemcpyHostToDevice ) );
     HIP_TRY_H( hipMemcpy( h->d_mats, mats.data(), sizeof( GMat ) * scene->n_nodes, hipMemcpyHostToDevice ) );
-    if( scene->n_elems ) HIP_TRY_H( hipMemcpy( h->d_elems, scene->elems, sizeof( int32_t ) * scene->n_elems, hipMemcpyHostToDevice ) );
+    HIP_TRY_H( hipMemcpy( h->d_elems, elems2.data(), sizeof( int32_t ) * elems2.size(), hipMemcpyHostToDevice ) );
     h->dev.nodes = ( NodeP )h->d_nodes;
     h->dev.mats = ( MatP )h->d_mats;
     h->dev.elems = ( ElemP )h->d_elems;

@@ -87,9 +87,7 @@ def test_run_script_renders_and_writes_pnm(oracle, tmp_path):
     sc = A.Scene.from_script(p, A.Scene.AUTOENV_GPU)
     flat = sc.flatten()
     cpu = oracle.render_positions(flat, S.positions(flat), linear=False)
-    want = A.cps_from_cl(cpu).reshape(img.shape[0], img.shape[1])
-    got = img[..., 0].astype(np.uint32) | img[..., 1].astype(np.uint32) << 8 | img[..., 2].astype(np.uint32) << 16
-    assert np.array_equal(got, want)
+    assert np.array_equal(img, A.cps_from_cl(cpu).reshape(img.shape))
 
 
 def test_cli_sigint_saves_and_recovers(tmp_path):
