@@ -540,17 +540,28 @@ template< class NP > DEV int distance_side( NP o, V3 pos )   /* objects.c:961-96
 }
 
 /* ------------------------------------------------------------------------------------------------------------------ */
-/* side machine: obj_side (objects.c:365-370) over the CSG tree, iteratively.  The innermost composite's frame lives
- * in registers; the scratch stack is touched only when a composite is nested inside a composite. */
-struct SideFrame { int node; int pc; V3 pos; };
+/* CSG machines.  obj_side and obj_ray_hit recurse through pair / neg / scale nodes in the reference; here they are
+ * per-lane state machines.  The innermost composite's frame lives in registers; enclosing frames sit on a per-lane
+ * stack.  Stack traffic is scratch traffic, and at full occupancy scratch does not fit L2 -- round-1 profiles showed
+ * the machine kernels moving ~390 GB per 1080p frame through HBM at 3.7-4.7 TB/s, i.e. bound by their own stacks.
+ * Frames are therefore as small as the algorithm allows:
+ *   side frame  4 B   node << 2 | pc.  The position is the same for every frame unless a scale wrapper intervenes;
+ *                     a scale wrapper parks the outer position on a small auxiliary stack.
+ *   hit frame  12 B   node / pc / swapped / inherit packed into one word + ONE double: a1 while the second child is
+ *                     evaluated (pc 2), the walk offset afterwards (pc 3), d_factor for a scale wrapper
+ *             +24 B   n1, only when normals are wanted (transition hits; never for occlusion tests).
+ *   The origin a frame received is not stored: a child evaluated at its parent's own origin inherits it (the common
+ *   case); only children entered from the alternating walk or below a scale wrapper park the parent's origin (and the
+ *   wrapper its direction) on the auxiliary stack. */
+#define ACN_PACK_SIDE( node, pc ) ( ( ( uint32_t )( node ) << 2 ) | ( uint32_t )( pc ) )
 
 template< class SR, class CT >
 DEV_SIDE int obj_side_dev( SR sc, int root, V3 pos, CT* cnt )
 {
-    SideFrame st[ ACN_CSG_MAX_DEPTH ];
-    SideFrame cur;
-    cur.node = 0; cur.pc = 0; cur.pos = pos;
-    int depth = 0;
+    uint32_t st[ ACN_CSG_MAX_DEPTH ];
+    V3 aux[ ACN_CSG_MAX_DEPTH ];
+    uint32_t cur = 0;
+    int depth = 0, na = 0;
     int node = root;
     int r = 1;
     for( ;; )
@@ -583,9 +594,10 @@ DEV_SIDE int obj_side_dev( SR sc, int root, V3 pos, CT* cnt )
         {
             if( depth > 0 ) st[ depth - 1 ] = cur;
             depth++;
-            cur.node = node; cur.pc = 1; cur.pos = pos;
+            cur = ACN_PACK_SIDE( node, 1 );
             if( type == ACN_SCALE )   /* objects.c:1439-1443 */
             {
+                aux[ na++ ] = pos;    /* na <= depth <= ACN_CSG_MAX_DEPTH */
                 M3 rax = node_rax( n );
                 V3 p = m_mlv( rax, v_sub( pos, ld3( n->pos ) ) );
                 pos = v_mld( p, mk( n->prm[ 0 ], n->prm[ 1 ], n->prm[ 2 ] ) );
@@ -597,17 +609,19 @@ DEV_SIDE int obj_side_dev( SR sc, int root, V3 pos, CT* cnt )
         while( have )
         {
             if( depth == 0 ) return r;
-            auto fn = &sc.nodes[ cur.node ];
+            int cnode = ( int )( cur >> 2 );
+            auto fn = &sc.nodes[ cnode ];
             int ftype = fn->type;
             bool done = true;
             if( ftype == ACN_NEG ) r = -r;                                   /* objects.c:1341-1344 */
-            else if( ftype != ACN_SCALE )
+            else if( ftype == ACN_SCALE ) pos = aux[ --na ];
+            else
             {
                 int want = ( ftype == ACN_PAIR_INSIDE ) ? -1 : 1;           /* objects.c:1096-1099, 1253-1256 */
-                if( cur.pc == 1 )
+                if( ( cur & 3u ) == 1u )
                 {
                     if( r != want ) r = -want;
-                    else { cur.pc = 2; node = fn->child1; pos = cur.pos; done = false; have = false; }
+                    else { cur = ACN_PACK_SIDE( cnode, 2 ); node = fn->child1; done = false; have = false; }
                 }
                 else
                 {
@@ -624,16 +638,12 @@ DEV_SIDE int obj_side_dev( SR sc, int root, V3 pos, CT* cnt )
 }
 
 /* ------------------------------------------------------------------------------------------------------------------ */
-/* hit machine: obj_ray_hit (objects.c:261-284) with pair / neg / scale recursion unrolled into frames; same
- * register-resident innermost frame. */
-struct HitFrame
-{
-    int node; short pc; short swapped;
-    double a1;        /* pair: a1 | scale: d_factor */
-    double offs;      /* pair: the walk offset */
-    V3 n1;            /* pair: n1 | scale: saved ray direction */
-    V3 rp;            /* origin of the ray this call received */
-};
+/* hit machine: obj_ray_hit (objects.c:261-284) with pair / neg / scale recursion unrolled into frames */
+#define ACN_HW_PC( w )       ( ( w ) & 3u )
+#define ACN_HW_SWAPPED( w )  ( ( ( w ) >> 2 ) & 1u )
+#define ACN_HW_INHERIT( w )  ( ( ( w ) >> 3 ) & 1u )
+#define ACN_HW_NODE( w )     ( ( int )( ( w ) >> 4 ) )
+#define ACN_HW_PACK( node, pc, swapped, inherit ) ( ( ( uint32_t )( node ) << 4 ) | ( ( uint32_t )( inherit ) << 3 ) | ( ( uint32_t )( swapped ) << 2 ) | ( uint32_t )( pc ) )
 
 template< class NP > DEV V3 roughness_normal( NP hdr, V3 n, V3 hit_pos )   /* objects.c:267-282 */
 {
@@ -651,10 +661,16 @@ template< class NP > DEV V3 roughness_normal( NP hdr, V3 n, V3 hit_pos )   /* ob
 template< class SR, class CT >
 DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3* out_nor, CT* cnt )
 {
-    HitFrame st[ ACN_CSG_MAX_DEPTH ];
-    HitFrame cur;
-    cur.node = 0; cur.pc = 0; cur.swapped = 0; cur.a1 = 0; cur.offs = 0; cur.n1 = mk( 0, 0, 0 ); cur.rp = rp;
-    int depth = 0;
+    uint32_t st_w[ ACN_CSG_MAX_DEPTH ];
+    double   st_a[ ACN_CSG_MAX_DEPTH ];
+    V3       st_n[ ACN_CSG_MAX_DEPTH ];     /* touched only when want_nor */
+    V3       aux[ 2 * ACN_CSG_MAX_DEPTH ];  /* parked origins / directions */
+    uint32_t cur_w = 0;
+    double cur_a = 0;                       /* pair: a1 (pc 2), walk offset (pc 3) | scale: d_factor */
+    V3 cur_n1 = mk( 0, 0, 0 );
+    V3 cur_rp = rp;                         /* origin of the ray the current frame received */
+    bool rp_derived = false;                /* rp differs from cur_rp (set by the walk and by scale wrappers) */
+    int depth = 0, na = 0;
     int node = root;
     double ret_a = F3_INF;
     V3 ret_n = mk( 0, 0, 0 );
@@ -687,9 +703,16 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
         }
         else
         {
-            if( depth > 0 ) st[ depth - 1 ] = cur;
+            if( depth > 0 )
+            {
+                st_w[ depth - 1 ] = cur_w; st_a[ depth - 1 ] = cur_a;
+                if( want_nor ) st_n[ depth - 1 ] = cur_n1;
+            }
             depth++;
-            cur.node = node; cur.pc = 1; cur.swapped = 0; cur.rp = rp;
+            if( rp_derived ) aux[ na++ ] = cur_rp;      /* na <= 2 * depth */
+            cur_w = ACN_HW_PACK( node, 1, 0, rp_derived ? 0 : 1 );
+            cur_rp = rp;
+            rp_derived = false;
             if( type == ACN_SCALE )   /* objects.c:1418-1428 */
             {
                 M3 rax = node_rax( n );
@@ -699,8 +722,9 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
                 double d_length = acn_sqrt( v_sqr( d2 ) );
                 double d_factor = ( d_length > 0 ) ? ( 1.0 / d_length ) : 0;
                 d2 = v_mlf( d2, d_factor );
-                cur.n1 = rd; cur.a1 = d_factor;
+                aux[ na++ ] = rd; cur_a = d_factor;
                 rp = p2; rd = d2;
+                rp_derived = true;
             }
             node = n->child0;
             have = false;
@@ -715,7 +739,8 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
                 if( want_nor && ret_a < F3_INF ) *out_nor = ret_n;
                 return ret_a;
             }
-            auto fn = &sc.nodes[ cur.node ];
+            int cnode = ACN_HW_NODE( cur_w );
+            auto fn = &sc.nodes[ cnode ];
             int ftype = fn->type;
             bool done = true;
             if( ftype == ACN_NEG )   /* objects.c:1329-1339 */
@@ -725,7 +750,7 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
             else if( ftype == ACN_SCALE )   /* objects.c:1430-1437 */
             {
                 double a1 = ret_a + F3_EPS;
-                rd = cur.n1;
+                rd = aux[ --na ];
                 if( a1 < F3_INF )
                 {
                     if( want_nor )
@@ -733,7 +758,7 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
                         V3 n1 = v_mld( ret_n, mk( fn->prm[ 0 ], fn->prm[ 1 ], fn->prm[ 2 ] ) );
                         ret_n = v_of_length( m_tmlv( node_rax( fn ), n1 ), 1.0 );
                     }
-                    ret_a = a1 * cur.a1 - F3_EPS;
+                    ret_a = a1 * cur_a - F3_EPS;
                 }
                 else
                 {
@@ -743,31 +768,34 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
             else   /* pair: objects.c:1052-1094 / 1209-1251 */
             {
                 int want = ( ftype == ACN_PAIR_INSIDE ) ? -1 : 1;
-                if( cur.pc == 1 )
+                uint32_t pc = ACN_HW_PC( cur_w );
+                if( pc == 1 )
                 {
-                    cur.a1 = ret_a; cur.n1 = ret_n; cur.pc = 2;
-                    node = fn->child1; rp = cur.rp;
+                    cur_a = ret_a; cur_n1 = ret_n;
+                    cur_w = ACN_HW_PACK( cnode, 2, 0, ACN_HW_INHERIT( cur_w ) );
+                    node = fn->child1; rp = cur_rp; rp_derived = false;
                     done = false; have = false;
                 }
-                else if( cur.pc == 2 )
+                else if( pc == 2 )
                 {
-                    double a1 = cur.a1, a2 = ret_a;
-                    if( a1 < a2 && obj_side_dev( sc, fn->child1, ray_pos( cur.rp, rd, a1 ), cnt ) == want )
+                    double a1 = cur_a, a2 = ret_a;
+                    if( a1 < a2 && obj_side_dev( sc, fn->child1, ray_pos( cur_rp, rd, a1 ), cnt ) == want )
                     {
-                        ret_a = a1; ret_n = cur.n1;
+                        ret_a = a1; ret_n = cur_n1;
                     }
                     else if( a2 >= F3_INF )
                     {
                         ret_a = F3_INF;
                     }
-                    else if( obj_side_dev( sc, fn->child0, ray_pos( cur.rp, rd, a2 ), cnt ) == want )
+                    else if( obj_side_dev( sc, fn->child0, ray_pos( cur_rp, rd, a2 ), cnt ) == want )
                     {
                         /* ret_a = a2, ret_n = n2 already */
                     }
                     else
                     {
-                        cur.offs = a2; cur.swapped = 0; cur.pc = 3;
-                        node = fn->child0; rp = ray_pos( cur.rp, rd, cur.offs );
+                        cur_a = a2;   /* the walk offset */
+                        cur_w = ACN_HW_PACK( cnode, 3, 0, ACN_HW_INHERIT( cur_w ) );
+                        node = fn->child0; rp = ray_pos( cur_rp, rd, cur_a ); rp_derived = true;
                         done = false; have = false;
                     }
                 }
@@ -780,24 +808,26 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
                     }
                     else
                     {
-                        V3 walk_p = ray_pos( cur.rp, rd, cur.offs );
-                        int obj2 = cur.swapped ? fn->child0 : fn->child1;
+                        V3 walk_p = ray_pos( cur_rp, rd, cur_a );
+                        uint32_t swapped = ACN_HW_SWAPPED( cur_w );
+                        int obj2 = swapped ? fn->child0 : fn->child1;
                         if( obj_side_dev( sc, obj2, ray_pos( walk_p, rd, a ), cnt ) == want )
                         {
-                            ret_a = cur.offs + a;   /* ret_n = n1 of the last child call */
+                            ret_a = cur_a + a;   /* ret_n = n1 of the last child call */
                         }
                         else
                         {
-                            cur.offs += a + 2 * F3_EPS;
-                            if( !( cur.offs < F3_INF ) )
+                            cur_a += a + 2 * F3_EPS;
+                            if( !( cur_a < F3_INF ) )
                             {
                                 ret_a = F3_INF;
                             }
                             else
                             {
-                                cur.swapped ^= 1;
-                                node = cur.swapped ? fn->child1 : fn->child0;
-                                rp = ray_pos( cur.rp, rd, cur.offs );
+                                swapped ^= 1u;
+                                cur_w = ACN_HW_PACK( cnode, 3, swapped, ACN_HW_INHERIT( cur_w ) );
+                                node = swapped ? fn->child1 : fn->child0;
+                                rp = ray_pos( cur_rp, rd, cur_a ); rp_derived = true;
                                 done = false; have = false;
                             }
                         }
@@ -807,10 +837,16 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
             if( done )
             {
                 /* POST of the composite itself (objects.c:266-282), then hand its result to its parent */
-                rp = cur.rp;
+                rp = cur_rp;
                 if( want_nor && ret_a < F3_INF && fn->surface_roughness > 0 ) ret_n = roughness_normal( fn, ret_n, ray_pos( rp, rd, ret_a ) );
+                if( !ACN_HW_INHERIT( cur_w ) ) cur_rp = aux[ --na ];
+                rp_derived = false;
                 depth--;
-                if( depth > 0 ) cur = st[ depth - 1 ];
+                if( depth > 0 )
+                {
+                    cur_w = st_w[ depth - 1 ]; cur_a = st_a[ depth - 1 ];
+                    if( want_nor ) cur_n1 = st_n[ depth - 1 ];
+                }
             }
         }
     }
