@@ -104,6 +104,14 @@ typedef const acn_texture ACN_CONST* TexP;
 /* node array staged in LDS (per workgroup) for the kernels whose node accesses are per-lane */
 #define ACN_LDS __attribute__( ( address_space( 3 ) ) )
 typedef const GNode ACN_LDS* LdsNodeP;
+typedef double ACN_LDS* LdsF64P;
+typedef uint32_t ACN_LDS* LdsU32P;
+/* dynamic LDS of the machine kernels: [ staged node array (optional) ][ CSG stacks of the block's 256 lanes ] */
+extern __shared__ __attribute__( ( aligned( 16 ) ) ) double acn_lds_raw[];
+#define ACN_LDS_DEPTH 8                 /* stack levels kept in LDS; deeper nesting continues in scratch */
+#define ACN_LDS_LANES 256               /* block size of the kernels that provide the stack area */
+#define ACN_LDS_STACK_BYTES ( ACN_LDS_DEPTH * ACN_LDS_LANES * 16 )   /* per level and lane: a 8 B, w 4 B, side 4 B */
+#define ACN_NO_LDS_STACK 0xFFFFFFFFu
 
 /* device-resident scene, parameterised by where the node array is read from */
 template< class NP >
@@ -120,6 +128,7 @@ struct DevSceneT
     M3 camera_rotation;
     double unit_f;
     uint32_t* flags;     /* device word for ACN_FLAG_* error bits */
+    uint32_t lds_stack;  /* byte offset of the CSG stack area in dynamic LDS, ACN_NO_LDS_STACK if the kernel has none */
 };
 typedef DevSceneT< NodeP > DevScene;
 
@@ -130,7 +139,7 @@ __device__ __forceinline__ DevSceneT< NP2 > scene_rebind( const DevScene& sc, NP
     DevSceneT< NP2 > r;
     r.nodes = nodes; r.mats = sc.mats; r.elems = sc.elems; r.textures = sc.textures;
     r.light_root = sc.light_root; r.matter_root = sc.matter_root; r.n_nodes = sc.n_nodes; r.n_elems = sc.n_elems;
-    r.prm = sc.prm; r.camera_rotation = sc.camera_rotation; r.unit_f = sc.unit_f; r.flags = sc.flags;
+    r.prm = sc.prm; r.camera_rotation = sc.camera_rotation; r.unit_f = sc.unit_f; r.flags = sc.flags; r.lds_stack = sc.lds_stack;
     return r;
 }
 
@@ -158,11 +167,11 @@ template<> struct Cnt< false >
 
 /* the two read-only scene arrays, passed BY VALUE into the non-inlined machines (global address space, so the
  * scene struct is never forced into scratch) */
-template< class NP > struct SceneRefT { NP nodes; ElemP elems; uint32_t* flags; uint32_t n_elems; };
+template< class NP > struct SceneRefT { NP nodes; ElemP elems; uint32_t* flags; uint32_t n_elems; uint32_t lds_stack; };
 #define ACN_FLAG_TASK_OVERFLOW  1u
 #define ACN_FLAG_CHILD_OVERFLOW 2u
 #define ACN_FLAG_STACK_OVERFLOW 4u   /* CSG / compound / ray stack exhausted: the result would be wrong, the call fails */
-template< class NP > __device__ __forceinline__ SceneRefT< NP > sref( const DevSceneT< NP >& sc ) { SceneRefT< NP > r; r.nodes = sc.nodes; r.elems = sc.elems; r.flags = sc.flags; r.n_elems = sc.n_elems; return r; }
+template< class NP > __device__ __forceinline__ SceneRefT< NP > sref( const DevSceneT< NP >& sc ) { SceneRefT< NP > r; r.nodes = sc.nodes; r.elems = sc.elems; r.flags = sc.flags; r.n_elems = sc.n_elems; r.lds_stack = sc.lds_stack; return r; }
 
 /* ---- vectors.h ---- */
 DEV V3 mk( double x, double y, double z ) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
@@ -560,6 +569,8 @@ DEV_SIDE int obj_side_dev( SR sc, int root, V3 pos, CT* cnt )
 {
     uint32_t st[ ACN_CSG_MAX_DEPTH ];
     V3 aux[ ACN_CSG_MAX_DEPTH ];
+    const bool lds = sc.lds_stack != ACN_NO_LDS_STACK;
+    LdsU32P ls = ( LdsU32P )( ( char ACN_LDS* )acn_lds_raw + sc.lds_stack ) + ACN_LDS_DEPTH * ACN_LDS_LANES * 3 + threadIdx.x;
     uint32_t cur = 0;
     int depth = 0, na = 0;
     int node = root;
@@ -592,7 +603,10 @@ DEV_SIDE int obj_side_dev( SR sc, int root, V3 pos, CT* cnt )
         }
         else
         {
-            if( depth > 0 ) st[ depth - 1 ] = cur;
+            if( depth > 0 )
+            {
+                if( lds && depth <= ACN_LDS_DEPTH ) ls[ ( depth - 1 ) * ACN_LDS_LANES ] = cur; else st[ depth - 1 ] = cur;
+            }
             depth++;
             cur = ACN_PACK_SIDE( node, 1 );
             if( type == ACN_SCALE )   /* objects.c:1439-1443 */
@@ -631,7 +645,7 @@ DEV_SIDE int obj_side_dev( SR sc, int root, V3 pos, CT* cnt )
             if( done )
             {
                 depth--;
-                if( depth > 0 ) cur = st[ depth - 1 ];
+                if( depth > 0 ) cur = ( lds && depth <= ACN_LDS_DEPTH ) ? ls[ ( depth - 1 ) * ACN_LDS_LANES ] : st[ depth - 1 ];
             }
         }
     }
@@ -665,6 +679,9 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
     double   st_a[ ACN_CSG_MAX_DEPTH ];
     V3       st_n[ ACN_CSG_MAX_DEPTH ];     /* touched only when want_nor */
     V3       aux[ 2 * ACN_CSG_MAX_DEPTH ];  /* parked origins / directions */
+    const bool lds = sc.lds_stack != ACN_NO_LDS_STACK;
+    LdsF64P la = ( LdsF64P )( ( char ACN_LDS* )acn_lds_raw + sc.lds_stack ) + threadIdx.x;
+    LdsU32P lw = ( LdsU32P )( ( char ACN_LDS* )acn_lds_raw + sc.lds_stack ) + ACN_LDS_DEPTH * ACN_LDS_LANES * 2 + threadIdx.x;
     uint32_t cur_w = 0;
     double cur_a = 0;                       /* pair: a1 (pc 2), walk offset (pc 3) | scale: d_factor */
     V3 cur_n1 = mk( 0, 0, 0 );
@@ -705,7 +722,8 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
         {
             if( depth > 0 )
             {
-                st_w[ depth - 1 ] = cur_w; st_a[ depth - 1 ] = cur_a;
+                if( lds && depth <= ACN_LDS_DEPTH ) { lw[ ( depth - 1 ) * ACN_LDS_LANES ] = cur_w; la[ ( depth - 1 ) * ACN_LDS_LANES ] = cur_a; }
+                else                                { st_w[ depth - 1 ] = cur_w; st_a[ depth - 1 ] = cur_a; }
                 if( want_nor ) st_n[ depth - 1 ] = cur_n1;
             }
             depth++;
@@ -844,7 +862,8 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
                 depth--;
                 if( depth > 0 )
                 {
-                    cur_w = st_w[ depth - 1 ]; cur_a = st_a[ depth - 1 ];
+                    if( lds && depth <= ACN_LDS_DEPTH ) { cur_w = lw[ ( depth - 1 ) * ACN_LDS_LANES ]; cur_a = la[ ( depth - 1 ) * ACN_LDS_LANES ]; }
+                    else                                { cur_w = st_w[ depth - 1 ]; cur_a = st_a[ depth - 1 ]; }
                     if( want_nor ) cur_n1 = st_n[ depth - 1 ];
                 }
             }

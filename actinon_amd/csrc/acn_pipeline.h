@@ -342,11 +342,10 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
  * are rebuilt inside (scene arrays are then read through the constant address space, see acn_device.h). */
 #define ACN_SCENE_PARAMS  DevScene sc_in, const GNode* __restrict__ p_nodes, const GMat* __restrict__ p_mats, const int32_t* __restrict__ p_elems, const acn_texture* __restrict__ p_textures
 #define ACN_SCENE_ARGS( h ) ( h )->dev, ( h )->d_nodes, ( h )->d_mats, ( h )->d_elems, ( h )->d_textures
-#define ACN_SCENE_VIEW    DevScene sc = sc_in; sc.nodes = ( NodeP )p_nodes; sc.mats = ( MatP )p_mats; sc.elems = ( ElemP )p_elems; sc.textures = ( TexP )p_textures; sc.flags = p_counts + QC_FLAGS;
+#define ACN_SCENE_VIEW    DevScene sc = sc_in; sc.nodes = ( NodeP )p_nodes; sc.mats = ( MatP )p_mats; sc.elems = ( ElemP )p_elems; sc.textures = ( TexP )p_textures; sc.flags = p_counts + QC_FLAGS; sc.lds_stack = ACN_NO_LDS_STACK;
 
 /* LDS staging of the node array (kernels whose node reads are per-lane: the CSG machines).  The block copies the
  * GNode array into dynamic shared memory once; per-lane node reads then are ds_read instead of global loads. */
-extern __shared__ __attribute__( ( aligned( 16 ) ) ) double acn_lds_raw[];
 #define ACN_STAGE_NODES( sc ) \
     { \
         const double* src_ = ( const double* )p_nodes; \
@@ -430,6 +429,7 @@ void k_trace_rays( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __res
 {
     ACN_SCENE_VIEW
     ACN_WALK_QUEUE_VIEW
+    sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
     if constexpr( LDS )
     {
         ACN_STAGE_NODES( sc )
@@ -660,6 +660,7 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
                     unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_SCENE_VIEW
+    sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     Cnt< COUNT > cnt;
     cnt.clear();
@@ -682,6 +683,7 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
                   uint32_t* __restrict__ p_counts, unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_SCENE_VIEW
+    sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     Cnt< COUNT > cnt;
     cnt.clear();

@@ -401,6 +401,7 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
         h->lds_bytes = need <= lds_max ? need : 0;
     }
     h->dev.flags = h->q.counts + QC_FLAGS;
+    h->dev.lds_stack = ACN_NO_LDS_STACK;
     HIP_TRY_H( hipMemset( h->q.counts, 0, sizeof( uint32_t ) * QC_N ) );
     /* camera basis on the device so that it shares the device's arithmetic */
     {
@@ -548,7 +549,7 @@ static int walk_passes( acn_scene_handle* h, uint32_t n_in, int* cur, hipStream_
         int in = *cur, out = 1 - in;
         HIP_TRY( hipMemsetAsync( h->q.counts + QC_RAYS, 0, sizeof( uint32_t ), stream ) );
         if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
-#define ACN_LAUNCH_TRACE( P, C, L, N, ... ) hipLaunchKernelGGL( ( k_trace_rays< P, C, L > ), dim3( ( ( N ) + 255 ) / 256 ), dim3( 256 ), ( L ) ? h->lds_bytes : 0, stream, \
+#define ACN_LAUNCH_TRACE( P, C, L, N, ... ) hipLaunchKernelGGL( ( k_trace_rays< P, C, L > ), dim3( ( ( N ) + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + ACN_LDS_STACK_BYTES, stream, \
             ACN_SCENE_ARGS( h ), __VA_ARGS__, h->d_accum, h->d_counters )
 #define ACN_DISPATCH_TRACE( P, N, ... ) do { \
             if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_TRACE( P, true, true, N, __VA_ARGS__ ); else ACN_LAUNCH_TRACE( P, true, false, N, __VA_ARGS__ ); } \
@@ -606,7 +607,7 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
             if( n_hs )
             {
                 if( ( st = stage_begin( h, 3, stream ) ) != ACN_OK ) return st;
-#define ACN_LAUNCH_HS( C, L ) hipLaunchKernelGGL( ( k_hard_shadow< C, L > ), dim3( ( n_hs + 255 ) / 256 ), dim3( 256 ), ( L ) ? h->lds_bytes : 0, stream, ACN_SCENE_ARGS( h ), \
+#define ACN_LAUNCH_HS( C, L ) hipLaunchKernelGGL( ( k_hard_shadow< C, L > ), dim3( ( n_hs + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + ACN_LDS_STACK_BYTES, stream, ACN_SCENE_ARGS( h ), \
                     ( const HardShadow* )h->q.hard_shadow, n_hs, h->q.counts, h->d_accum, h->d_counters )
                 if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_HS( true, true ); else ACN_LAUNCH_HS( true, false ); }
                 else                { if( h->lds_bytes ) ACN_LAUNCH_HS( false, true ); else ACN_LAUNCH_HS( false, false ); }
@@ -616,7 +617,7 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
             if( n_hp )
             {
                 if( ( st = stage_begin( h, 3, stream ) ) != ACN_OK ) return st;
-#define ACN_LAUNCH_HP( C, L ) hipLaunchKernelGGL( ( k_hard_path< C, L > ), dim3( ( n_hp + 255 ) / 256 ), dim3( 256 ), ( L ) ? h->lds_bytes : 0, stream, ACN_SCENE_ARGS( h ), \
+#define ACN_LAUNCH_HP( C, L ) hipLaunchKernelGGL( ( k_hard_path< C, L > ), dim3( ( n_hp + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + ACN_LDS_STACK_BYTES, stream, ACN_SCENE_ARGS( h ), \
                     ( const HardPath* )h->q.hard_path, n_hp, h->q.children, h->q.child_cap, h->q.counts, h->d_accum, h->d_counters )
                 if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_HP( true, true ); else ACN_LAUNCH_HP( true, false ); }
                 else                { if( h->lds_bytes ) ACN_LAUNCH_HP( false, true ); else ACN_LAUNCH_HP( false, false ); }
