@@ -429,7 +429,7 @@ void k_trace_rays( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __res
 {
     ACN_SCENE_VIEW
     ACN_WALK_QUEUE_VIEW
-    sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
+    if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
     if constexpr( LDS )
     {
         ACN_STAGE_NODES( sc )
@@ -660,7 +660,7 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
                     unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_SCENE_VIEW
-    sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
+    if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     Cnt< COUNT > cnt;
     cnt.clear();
@@ -683,7 +683,7 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
                   uint32_t* __restrict__ p_counts, unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_SCENE_VIEW
-    sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
+    if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     Cnt< COUNT > cnt;
     cnt.clear();

@@ -42,6 +42,7 @@ struct acn_scene_handle
     unsigned long long* d_counters = nullptr;
     std::vector< StageEvents > events;  size_t events_used = 0;
     size_t lds_bytes = 0;                      /* > 0: the node array fits the LDS staging budget */
+    size_t lds_stack_bytes = 0;                /* > 0: the machine kernels keep their CSG stacks in LDS */
     bool leaf_lights = true;                   /* every light element is a plane / sphere */
     bool count_work = false;                   /* ACN_OPT_COUNT_WORK of the current call */
     uint64_t launches[ 4 ] = { 0, 0, 0, 0 };   /* walk, shade, finalize, hard-ray kernels */
@@ -395,13 +396,21 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
         }
     }
     {
-        size_t lds_max = 65536;
+        /* LDS plan of the machine kernels (160 KB per CU, 4 blocks of 256 lanes wanted per CU => 40 KB per block):
+         *   nodes + stacks   when the node array is small (<= 8 KB: wine_glass 6 KB);
+         *   nodes only       up to 40 KB (diamond): staging the per-lane node reads pays more than the stacks;
+         *   stacks only      beyond (the node array stays in global memory / L2).
+         * ACN_LDS_MAX (bytes of nodes that may be staged) and ACN_LDS_STACK=0|1 override. */
+        size_t lds_max = 40960;
         if( const char* e = getenv( "ACN_LDS_MAX" ) ) lds_max = ( size_t )atoll( e );
         size_t need = sizeof( GNode ) * ( size_t )scene->n_nodes;
         h->lds_bytes = need <= lds_max ? need : 0;
+        bool stack = h->lds_bytes == 0 || h->lds_bytes + ACN_LDS_STACK_BYTES <= 40960;
+        if( const char* e = getenv( "ACN_LDS_STACK" ) ) stack = atoi( e ) != 0;
+        h->lds_stack_bytes = stack ? ACN_LDS_STACK_BYTES : 0;
     }
     h->dev.flags = h->q.counts + QC_FLAGS;
-    h->dev.lds_stack = ACN_NO_LDS_STACK;
+    h->dev.lds_stack = h->lds_stack_bytes ? 0u : ACN_NO_LDS_STACK;   /* the kernels that own a stack area set the offset */
     HIP_TRY_H( hipMemset( h->q.counts, 0, sizeof( uint32_t ) * QC_N ) );
     /* camera basis on the device so that it shares the device's arithmetic */
     {
@@ -549,7 +558,7 @@ static int walk_passes( acn_scene_handle* h, uint32_t n_in, int* cur, hipStream_
         int in = *cur, out = 1 - in;
         HIP_TRY( hipMemsetAsync( h->q.counts + QC_RAYS, 0, sizeof( uint32_t ), stream ) );
         if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
-#define ACN_LAUNCH_TRACE( P, C, L, N, ... ) hipLaunchKernelGGL( ( k_trace_rays< P, C, L > ), dim3( ( ( N ) + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + ACN_LDS_STACK_BYTES, stream, \
+#define ACN_LAUNCH_TRACE( P, C, L, N, ... ) hipLaunchKernelGGL( ( k_trace_rays< P, C, L > ), dim3( ( ( N ) + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + h->lds_stack_bytes, stream, \
             ACN_SCENE_ARGS( h ), __VA_ARGS__, h->d_accum, h->d_counters )
 #define ACN_DISPATCH_TRACE( P, N, ... ) do { \
             if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_TRACE( P, true, true, N, __VA_ARGS__ ); else ACN_LAUNCH_TRACE( P, true, false, N, __VA_ARGS__ ); } \
@@ -607,7 +616,7 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
             if( n_hs )
             {
                 if( ( st = stage_begin( h, 3, stream ) ) != ACN_OK ) return st;
-#define ACN_LAUNCH_HS( C, L ) hipLaunchKernelGGL( ( k_hard_shadow< C, L > ), dim3( ( n_hs + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + ACN_LDS_STACK_BYTES, stream, ACN_SCENE_ARGS( h ), \
+#define ACN_LAUNCH_HS( C, L ) hipLaunchKernelGGL( ( k_hard_shadow< C, L > ), dim3( ( n_hs + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + h->lds_stack_bytes, stream, ACN_SCENE_ARGS( h ), \
                     ( const HardShadow* )h->q.hard_shadow, n_hs, h->q.counts, h->d_accum, h->d_counters )
                 if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_HS( true, true ); else ACN_LAUNCH_HS( true, false ); }
                 else                { if( h->lds_bytes ) ACN_LAUNCH_HS( false, true ); else ACN_LAUNCH_HS( false, false ); }
@@ -617,7 +626,7 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
             if( n_hp )
             {
                 if( ( st = stage_begin( h, 3, stream ) ) != ACN_OK ) return st;
-#define ACN_LAUNCH_HP( C, L ) hipLaunchKernelGGL( ( k_hard_path< C, L > ), dim3( ( n_hp + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + ACN_LDS_STACK_BYTES, stream, ACN_SCENE_ARGS( h ), \
+#define ACN_LAUNCH_HP( C, L ) hipLaunchKernelGGL( ( k_hard_path< C, L > ), dim3( ( n_hp + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + h->lds_stack_bytes, stream, ACN_SCENE_ARGS( h ), \
                     ( const HardPath* )h->q.hard_path, n_hp, h->q.children, h->q.child_cap, h->q.counts, h->d_accum, h->d_counters )
                 if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_HP( true, true ); else ACN_LAUNCH_HP( true, false ); }
                 else                { if( h->lds_bytes ) ACN_LAUNCH_HP( false, true ); else ACN_LAUNCH_HP( false, false ); }
@@ -822,7 +831,9 @@ extern "C" int acn_estimate_envelope( acn_scene_handle* h, int32_t node, uint64_
     V3* d_scratch = nullptr; double* d_out = nullptr;
     HIP_TRY( hipMalloc( &d_scratch, sizeof( V3 ) * ( samples ? samples : 1 ) ) );
     HIP_TRY( hipMalloc( &d_out, sizeof( double ) * 4 ) );
-    hipLaunchKernelGGL( k_estimate_envelope, dim3( 1 ), dim3( 1 ), 0, h->stream, h->dev, node, samples, rseed, radius_factor, d_scratch, d_out );
+    DevScene est_scene = h->dev;
+    est_scene.lds_stack = ACN_NO_LDS_STACK;   /* one lane, no dynamic LDS: the machine keeps its stacks in scratch */
+    hipLaunchKernelGGL( k_estimate_envelope, dim3( 1 ), dim3( 1 ), 0, h->stream, est_scene, node, samples, rseed, radius_factor, d_scratch, d_out );
     hipError_t e = hipGetLastError();
     if( e == hipSuccess ) e = hipStreamSynchronize( h->stream );
     if( e == hipSuccess ) e = hipMemcpy( out, d_out, sizeof( double ) * 4, hipMemcpyDeviceToHost );
