@@ -29,6 +29,7 @@ SCRIPTS = {
     "pyramid": "pyramid.acn",
     "ruby_heart": "ruby_heart.acn",
     "caustic_of_caustic": "caustic_of_caustic.acn",
+    "hanging_lamps_in_row": "hanging_lamps_in_row/hanging_lamps_in_row.acn",   # 28 439 nodes: lamps as nested compounds
 }
 
 

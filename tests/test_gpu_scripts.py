@@ -61,6 +61,7 @@ FIXTURES = {
     "paraffin_lamp": dict(image_width=48, image_height=72, direct_samples=8, path_samples=8),
     "hanging_lamp": dict(image_width=60, image_height=80, direct_samples=8, path_samples=8),
     "paraffin_lamp_on_ledge": dict(image_width=48, image_height=64, direct_samples=8, path_samples=8),
+    "hanging_lamps_in_row": dict(image_width=64, image_height=36, direct_samples=4, path_samples=4),
 }
 
 
