@@ -129,7 +129,11 @@ struct DevSceneT
     double unit_f;
     uint32_t* flags;     /* device word for ACN_FLAG_* error bits */
     uint32_t lds_stack;  /* byte offset of the CSG stack area in dynamic LDS, ACN_NO_LDS_STACK if the kernel has none */
+    uint32_t prune_base; /* elems[ prune_base + node ]: offset of the node's prune program in elems[], or -1 */
+    static constexpr bool prune = false;
 };
+/* the same scene for the kernel variants that run the interval-prune programs (only launched when the scene has any) */
+template< class NP > struct DevScenePT : DevSceneT< NP > { static constexpr bool prune = true; };
 typedef DevSceneT< NodeP > DevScene;
 
 /* the same scene with its node array read from another address space */
@@ -139,8 +143,15 @@ __device__ __forceinline__ DevSceneT< NP2 > scene_rebind( const DevScene& sc, NP
     DevSceneT< NP2 > r;
     r.nodes = nodes; r.mats = sc.mats; r.elems = sc.elems; r.textures = sc.textures;
     r.light_root = sc.light_root; r.matter_root = sc.matter_root; r.n_nodes = sc.n_nodes; r.n_elems = sc.n_elems;
-    r.prm = sc.prm; r.camera_rotation = sc.camera_rotation; r.unit_f = sc.unit_f; r.flags = sc.flags; r.lds_stack = sc.lds_stack;
+    r.prm = sc.prm; r.camera_rotation = sc.camera_rotation; r.unit_f = sc.unit_f; r.flags = sc.flags; r.lds_stack = sc.lds_stack; r.prune_base = sc.prune_base;
     return r;
+}
+
+template< bool PR, class NP2 >
+__device__ __forceinline__ auto scene_view( const DevScene& sc, NP2 nodes )
+{
+    if constexpr( PR ) { DevScenePT< NP2 > r; static_cast< DevSceneT< NP2 >& >( r ) = scene_rebind( sc, nodes ); return r; }
+    else return scene_rebind( sc, nodes );
 }
 
 enum
@@ -938,6 +949,174 @@ DEV bool surely_outside( const SC& sc, int node, V3 rp, V3 rd )
 }
 #define ACN_PRUNE_DEPTH 3
 
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* Interval pruning of big CSG objects.  For a root element with many nodes the upload step compiles a small postfix
+ * program (actinon_hip.hip: build_prune_programs) that computes a conservative parameter interval [ lo, hi ] of the
+ * ray: every t at which rp + t * rd could be classified "inside the object" by obj_side, or be reported as a hit,
+ * lies in it.  An empty interval means the reference returns f3_inf for the object and +1 for obj_side at every point
+ * it would look at (the argument of surely_outside, made sharper), so the object is skipped with results unchanged:
+ *   plane                     half line (linear inequality along the ray)
+ *   sphere, envelope          chord of the ball
+ *   squaroid                  roots of the quadric restricted to the ray when that restriction is convex (A > 0)
+ *   NEG( plane )              the complementary half line; any other complement: no statement (whole ray)
+ *   pair_inside               intersection of the children's intervals       pair_outside: hull of their union
+ *   scale, distance, subtrees beyond the program's budget: no statement beyond the node's envelope
+ * Conservative by construction: surfaces are widened by 1e-9 relative, every end point by ACN_IV_W = 1e-4 ray units
+ * (hits are reported f3_eps = 1e-6 before the surface and the alternating walk steps 2 * f3_eps at a time,
+ * objects.c:1080-1090) plus 1e-8 relative for root cancellation.  Directions are unit vectors at the call sites (the
+ * program never descends through a scale wrapper).  Program and node index are wave-uniform: every load is scalar and
+ * every branch of the interpreter loop is a scalar branch; the interval stack is six register pairs that shift. */
+struct Iv { double lo, hi; };
+#define ACN_IV_W 1.0e-4
+DEV Iv iv_all() { Iv r; r.lo = -ACN_IV_W; r.hi = F3_INF; return r; }
+DEV Iv iv_none() { Iv r; r.lo = 1.0; r.hi = 0.0; return r; }
+DEV bool iv_empty( Iv a ) { return !( a.lo <= a.hi ); }
+DEV Iv iv_and( Iv a, Iv b ) { Iv r; r.lo = f_max( a.lo, b.lo ); r.hi = f_min( a.hi, b.hi ); return r; }
+DEV Iv iv_or( Iv a, Iv b )
+{
+    if( iv_empty( a ) ) return b;
+    if( iv_empty( b ) ) return a;
+    Iv r; r.lo = f_min( a.lo, b.lo ); r.hi = f_max( a.hi, b.hi );
+    return r;
+}
+DEV double iv_widen_lo( double t ) { return t - ( ACN_IV_W + 1.0e-8 * f_abs( t ) ); }
+DEV double iv_widen_hi( double t ) { return t + ( ACN_IV_W + 1.0e-8 * f_abs( t ) ); }
+
+/* { t : ( rp + t rd - pos ) * nor <= 0 }, or >= 0 for the complement */
+DEV Iv iv_halfspace( V3 pos, V3 nor, V3 rp, V3 rd, bool complement )
+{
+    double s0 = v_sub_mlv( rp, pos, nor );
+    double s1 = v_mlv( nor, rd );
+    if( complement ) { s0 = -s0; s1 = -s1; }
+    s0 -= 1.0e-9 * ( f_abs( s0 ) + 1.0 );
+    Iv r = iv_all();
+    if( s1 > 0 )      r.hi = iv_widen_hi( -s0 / s1 );
+    else if( s1 < 0 ) r.lo = f_max( r.lo, iv_widen_lo( -s0 / s1 ) );
+    else if( s0 > 0 ) r = iv_none();
+    return r;
+}
+
+DEV Iv iv_ball( V3 c, double radius, V3 rp, V3 rd )
+{
+    V3 p = v_sub( rp, c );
+    double s = v_mlv( p, rd );
+    double rr = radius * radius, pp = v_sqr( p );
+    double q = pp - ( rr + 1.0e-9 * ( rr + pp ) + 1.0e-12 );
+    double disc = s * s - q;
+    if( !( disc >= 0 ) ) return iv_none();
+    double sq = acn_sqrt( disc );
+    Iv r; r.lo = iv_widen_lo( -s - sq ); r.hi = iv_widen_hi( -s + sq );
+    return iv_and( r, iv_all() );
+}
+
+template< class NP > DEV Iv iv_squaroid( NP o, V3 rp, V3 rd )
+{
+    M3 rax = node_rax( o );
+    V3 p = m_mlv( rax, v_sub( rp, ld3( o->pos ) ) );
+    V3 d = m_mlv( rax, rd );
+    double a = o->prm[ 0 ], b = o->prm[ 1 ], c = o->prm[ 2 ], r = o->prm[ 3 ];
+    double A = a * d.x * d.x + b * d.y * d.y + c * d.z * d.z;
+    double B = a * p.x * d.x + b * p.y * d.y + c * p.z * d.z;
+    double C = a * p.x * p.x + b * p.y * p.y + c * p.z * p.z + r;
+    double cmag = f_abs( a ) * p.x * p.x + f_abs( b ) * p.y * p.y + f_abs( c ) * p.z * p.z + f_abs( r );
+    double amag = f_abs( a ) * d.x * d.x + f_abs( b ) * d.y * d.y + f_abs( c ) * d.z * d.z;
+    C -= 1.0e-9 * cmag + 1.0e-12;
+    if( !( A > 1.0e-6 * amag ) ) return iv_all();   /* not convex along this ray, or ill conditioned: no statement */
+    double disc = B * B - A * C;
+    if( !( disc >= 0 ) ) return iv_none();
+    double sq = acn_sqrt( disc );
+    Iv iv; iv.lo = iv_widen_lo( ( -B - sq ) / A ); iv.hi = iv_widen_hi( ( -B + sq ) / A );
+    return iv_and( iv, iv_all() );
+}
+
+/* Two intervals per sub-object X (envelopes make them differ: obj_ray_hit tests an envelope once per RAY,
+ * objects.c:264, so hits may lie outside the envelope ball, while obj_side clips per POINT, objects.c:368):
+ *   H( X )  where a surface point of X can be reported as a hit (from any origin on the line),
+ *   S( X )  where a point can be classified "inside X".
+ *   leaf            H = S = primitive interval; plane: H is the crossing point alone (plane_ray_hit's own expression)
+ *   NEG( X )        H = H( X ),  S = complement (a half line for a plane, else the whole ray)
+ *   pair_inside     H = hull( H(A) n S(B), H(B) n S(A) )    S = S(A) n S(B)      (objects.c:1057-1092: a reported
+ *                                                            hit is a surface point of one child inside the other)
+ *   pair_outside    H = hull( H(A) u H(B) )                 S = hull( S(A) u S(B) )
+ *   envelope E      ray misses E: H = S = empty; else S = S n chord( E ), H unchanged
+ * The object is skipped iff H( root ) has no point in [ -W, limit + W ]. */
+enum { ACN_PO_END = 0, ACN_PO_PLANE, ACN_PO_SPHERE, ACN_PO_QUAD, ACN_PO_ALL, ACN_PO_NEG, ACN_PO_AND, ACN_PO_OR, ACN_PO_ENV };
+#define ACN_PO( op, node ) ( ( uint32_t )( op ) | ( ( uint32_t )( node ) << 4 ) )
+#ifdef ACN_PRUNE_CHECK
+#define ACN_FAST_PRUNE( ... ) false
+#else
+#define ACN_FAST_PRUNE( ... ) prune_run( __VA_ARGS__ )
+#endif
+#define ACN_PRUNE_STACK 5
+
+/* true: `node` (a wave-uniform index) cannot report a hit at any t <= limit.  false also when it has no program. */
+template< class NP >
+DEV bool prune_exec( NP nodes, ElemP elems, int pc, V3 rp, V3 rd, double limit );
+
+/* true: `node` (a wave-uniform index) cannot report a hit at any t <= limit.  false also when it has no program.
+ * Compiled in only for the DevScenePT kernel variants: the interval stack costs ~40 VGPRs, which the spill-free
+ * k_shade of scenes without programs (wine_glass) must not pay for. */
+template< class SC >
+DEV bool prune_run( const SC& sc, int node, V3 rp, V3 rd, double limit )
+{
+    if constexpr( SC::prune )
+    {
+        int pc = sc.elems[ sc.prune_base + ( uint32_t )node ];
+        if( pc < 0 ) return false;
+        return prune_exec( sc.nodes, sc.elems, pc, rp, rd, limit );
+    }
+    else return false;
+}
+
+template< class NP >
+DEV bool prune_exec( NP nodes, ElemP elems, int pc, V3 rp, V3 rd, double limit )
+{
+    Iv h0 = iv_all(), h1 = iv_all(), h2 = iv_all(), h3 = iv_all(), h4 = iv_all();
+    Iv s0 = iv_all(), s1 = iv_all(), s2 = iv_all(), s3 = iv_all(), s4 = iv_all();
+    for( ;; pc++ )
+    {
+        uint32_t w = ( uint32_t )elems[ pc ];
+        uint32_t op = w & 15u;
+        if( op == ACN_PO_END ) break;
+        auto n = &nodes[ w >> 4 ];
+        if( op <= ACN_PO_ALL )
+        {
+            Iv xs = iv_all(), xh = iv_all();
+            if( op == ACN_PO_PLANE )
+            {
+                V3 pos = ld3( n->pos ), nor = ld3( n->rax + 6 );
+                xs = iv_halfspace( pos, nor, rp, rd, false );
+                double div = v_mlv( nor, rd );   /* plane_ray_hit (objects.c:530-541) */
+                if( div == 0 ) xh = iv_none();
+                else { double offs = v_sub_mlv( pos, rp, nor ) / div; xh.lo = iv_widen_lo( offs ); xh.hi = iv_widen_hi( offs ); xh = iv_and( xh, iv_all() ); }
+            }
+            else if( op == ACN_PO_SPHERE ) xs = xh = iv_ball( ld3( n->pos ), n->prm[ 0 ], rp, rd );
+            else if( op == ACN_PO_QUAD )   xs = xh = iv_squaroid( n, rp, rd );
+            h4 = h3; h3 = h2; h2 = h1; h1 = h0; h0 = xh;
+            s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = xs;
+        }
+        else if( op == ACN_PO_NEG )
+        {
+            /* complement: a plane's is the other half line (w carries the plane's node), anything else: no statement */
+            s0 = ( w >> 4 ) ? iv_halfspace( ld3( n->pos ), ld3( n->rax + 6 ), rp, rd, true ) : iv_all();
+        }
+        else if( op == ACN_PO_ENV )
+        {
+            if( !env_ray_hits( n, rp, rd ) ) { h0 = iv_none(); s0 = iv_none(); }   /* the machine's own test (objects.c:264) */
+            else s0 = iv_and( s0, iv_ball( ld3( n->env_pos ), n->env_radius, rp, rd ) );
+        }
+        else
+        {
+            if( op == ACN_PO_AND ) { h0 = iv_or( iv_and( h1, s0 ), iv_and( h0, s1 ) ); s0 = iv_and( s1, s0 ); }
+            else                   { h0 = iv_or( h1, h0 ); s0 = iv_or( s1, s0 ); }
+            h1 = h2; h2 = h3; h3 = h4;
+            s1 = s2; s2 = s3; s3 = s4;
+        }
+    }
+    h0.hi = f_min( h0.hi, iv_widen_hi( limit ) );
+    return iv_empty( h0 );
+}
+
 /* Hit test of ROOT element `e` (an index that is the same in every active lane of the wave, so the node is read
  * through the scalar cache into SGPRs and the type dispatch is a scalar branch): obj_ray_hit (objects.c:261-284)
  * for objects -- plane / sphere / squaroid inline, CSG and SDF objects through the hit machine -- and
@@ -953,7 +1132,17 @@ DEV double element_hit( const SC& sc, int e, V3 rp, V3 rd, V3* nor, int* hit_obj
     if( env && !env_ray_hits( n, rp, rd ) ) { cnt->inc( CNT_OBJ_HIT ); return F3_INF; }
     if( type > ACN_SQUAROID )
     {
+#ifdef ACN_PRUNE_CHECK
         if( type != ACN_DISTANCE && surely_outside< ACN_PRUNE_DEPTH >( sc, e, rp, rd ) ) { cnt->inc( CNT_OBJ_HIT ); return F3_INF; }
+        {
+            bool pr = type != ACN_DISTANCE && prune_run( sc, e, rp, rd, F3_INF );
+            V3 nn = mk( 0, 0, 0 );
+            double aa = obj_ray_hit_dev( sref( sc ), e, rp, rd, NOR, NOR ? nor : &nn, cnt );
+            if( pr && aa < F3_INF ) printf( "PRUNE VIOLATION e=%d a=%.17g rp=%.17g %.17g %.17g rd=%.17g %.17g %.17g\n", e, aa, rp.x, rp.y, rp.z, rd.x, rd.y, rd.z );
+            return aa;
+        }
+#endif
+        if( type != ACN_DISTANCE && ( surely_outside< ACN_PRUNE_DEPTH >( sc, e, rp, rd ) || prune_run( sc, e, rp, rd, F3_INF ) ) ) { cnt->inc( CNT_OBJ_HIT ); return F3_INF; }
         return obj_ray_hit_dev( sref( sc ), e, rp, rd, NOR, nor, cnt );   /* the machine redoes the envelope test */
     }
     cnt->inc( CNT_OBJ_HIT );
@@ -1063,7 +1252,7 @@ DEV int root_occluded_fast( const SC& sc, int cmp, V3 rp, V3 rd, double limit, C
             if( a <= limit ) return 1;
         }
         else if( type == ACN_COMPOUND || type == ACN_DISTANCE ? ( !node_has_env( n ) || env_ray_hits( n, rp, rd ) )
-                                                              : !surely_outside< ACN_PRUNE_DEPTH >( sc, element, rp, rd ) )
+                                                              : !( surely_outside< ACN_PRUNE_DEPTH >( sc, element, rp, rd ) || ACN_FAST_PRUNE( sc, element, rp, rd, limit ) ) )
         {
             hard = true;
         }
@@ -1089,7 +1278,7 @@ DEV double root_trans_hit_fast( const SC& sc, int cmp, V3 rp, V3 rd, Trans* tran
         if( !is_fast_type( type ) )
         {
             if( type == ACN_COMPOUND || type == ACN_DISTANCE ? ( !node_has_env( n ) || env_ray_hits( n, rp, rd ) )
-                                                             : !surely_outside< ACN_PRUNE_DEPTH >( sc, element, rp, rd ) ) h = true;
+                                                             : !( surely_outside< ACN_PRUNE_DEPTH >( sc, element, rp, rd ) || ACN_FAST_PRUNE( sc, element, rp, rd, F3_INF ) ) ) h = true;
             continue;
         }
         V3 nor = mk( 0, 0, 0 );

@@ -421,7 +421,7 @@ DEV void trace_rays_body( const DevScene& sc, const SCL& scl, const Queues& q, c
 #ifndef ACN_HPATH_WAVES
 #define ACN_HPATH_WAVES ACN_WALK_WAVES
 #endif
-template< bool PRIMARY, bool COUNT, bool LDS >
+template< bool PRIMARY, bool COUNT, bool LDS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_TRACE_WAVES )
 void k_trace_rays( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __restrict__ rays_in,
                    const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n,
@@ -433,11 +433,11 @@ void k_trace_rays( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __res
     if constexpr( LDS )
     {
         ACN_STAGE_NODES( sc )
-        trace_rays_body< PRIMARY, COUNT >( sc, scene_rebind( sc, ( LdsNodeP )acn_lds_raw ), q, rays_in, pos_xy, first_pixel, base, n, accum, counters );
+        trace_rays_body< PRIMARY, COUNT >( sc, scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), q, rays_in, pos_xy, first_pixel, base, n, accum, counters );
     }
     else
     {
-        trace_rays_body< PRIMARY, COUNT >( sc, sc, q, rays_in, pos_xy, first_pixel, base, n, accum, counters );
+        trace_rays_body< PRIMARY, COUNT >( sc, scene_view< PRUNE >( sc, sc.nodes ), q, rays_in, pos_xy, first_pixel, base, n, accum, counters );
     }
 }
 
@@ -484,7 +484,7 @@ template< int LPT > DEV uint64_t lcg_stride( uint64_t x )   /* jump by 2*LPT dra
 
 /* LEAF_LIGHTS: every light is a plane / sphere / squaroid-free leaf, so the kernel contains no call into the CSG
  * machine at all (the usual case); otherwise the light hit goes through the generic element test. */
-template< int LPT, bool COUNT, bool LEAF_LIGHTS >
+template< int LPT, bool COUNT, bool LEAF_LIGHTS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_SHADE_WAVES )
 void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t* __restrict__ idx, uint32_t n_tasks,
               HitRec* __restrict__ p_children, uint32_t child_cap, HardShadow* __restrict__ p_hard_shadow,
@@ -492,6 +492,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
               unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_SCENE_VIEW
+    const auto scp = scene_view< PRUNE >( sc, sc.nodes );   /* the scene as the two root-traversal fast paths see it */
     Queues q;
     q.tasks = nullptr; q.children = p_children; q.counts = p_counts; q.task_cap = 0; q.child_cap = child_cap;
     q.hard_shadow = p_hard_shadow; q.hard_path = p_hard_path; q.hard_cap = hard_cap; q.rays_out = nullptr; q.ray_cap = 0;
@@ -555,7 +556,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 double diff_sqr = v_diff_sqr( hit_pos, light_pos );
                 double local_intensity = ( diff_sqr > 0 ) ? ( radiance / diff_sqr ) : F3_MAG;
                 double c = local_intensity * weight * diffuse_intensity;
-                int occ = root_occluded_fast( sc, sc.matter_root, pos, out_d, a, &cnt );
+                int occ = root_occluded_fast( scp, sc.matter_root, pos, out_d, a, &cnt );
                 if( occ == 0 ) s += c;
                 /* hard shadow rays: compacted into the queue of k_hard_shadow, which adds c itself if unoccluded */
                 uint32_t hs = wave_alloc( &q.counts[ QC_HARD_SHADOW ], occ == 2 );
@@ -607,7 +608,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 if( live )
                 {
                     if( on_b > 0 ) weight = oren_nayar_weight( weight, theta_i, on_a, on_b, out_d, surface_d, ray_projection );
-                    a = root_trans_hit_fast( sc, sc.matter_root, pos, out_d, &trans, &hard, &cnt );
+                    a = root_trans_hit_fast( scp, sc.matter_root, pos, out_d, &trans, &hard, &cnt );
                 }
                 bool hit = live && !hard && a < sc.prm.max_path_length;
                 if( live && !hard && !hit ) bsum += weight * diffuse_intensity;
@@ -654,7 +655,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
 }
 
 /* the shadow rays k_shade could not decide inline: full occlusion test, one lane per ray */
-template< bool COUNT, bool LDS >
+template< bool COUNT, bool LDS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_WALK_WAVES )
 void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint32_t n, uint32_t* __restrict__ p_counts,
                     unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
@@ -669,15 +670,15 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
     {
         HardShadow r = recs[ i ];
         bool occ;
-        if constexpr( LDS ) occ = root_occluded( scene_rebind( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, r.limit, &cnt );
-        else                occ = root_occluded( sc, sc.matter_root, r.pos, r.d, r.limit, &cnt );
+        if constexpr( LDS ) occ = root_occluded( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, r.limit, &cnt );
+        else                occ = root_occluded( scene_view< PRUNE >( sc, sc.nodes ), sc.matter_root, r.pos, r.d, r.limit, &cnt );
         if( !occ ) pixel_add( accum, r.pixel, r.contrib );
     }
     wave_add_counters( counters, cnt );
 }
 
 /* the path rays k_shade could not finish inline: full transition hit; hits join the next level's HitRec queue */
-template< bool COUNT, bool LDS >
+template< bool COUNT, bool LDS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_HPATH_WAVES )
 void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t n, HitRec* __restrict__ p_children, uint32_t child_cap,
                   uint32_t* __restrict__ p_counts, unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
@@ -696,8 +697,8 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
     if( i < n )
     {
         r = recs[ i ];
-        if constexpr( LDS ) a = root_trans_hit( scene_rebind( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, &trans, &cnt );
-        else                a = root_trans_hit( sc, sc.matter_root, r.pos, r.d, &trans, &cnt );
+        if constexpr( LDS ) a = root_trans_hit( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, &trans, &cnt );
+        else                a = root_trans_hit( scene_view< PRUNE >( sc, sc.nodes ), sc.matter_root, r.pos, r.d, &trans, &cnt );
         hit = a < sc.prm.max_path_length;
         if( !hit )
         {

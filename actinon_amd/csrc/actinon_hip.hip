@@ -43,6 +43,7 @@ struct acn_scene_handle
     std::vector< StageEvents > events;  size_t events_used = 0;
     size_t lds_bytes = 0;                      /* > 0: the node array fits the LDS staging budget */
     size_t lds_stack_bytes = 0;                /* > 0: the machine kernels keep their CSG stacks in LDS */
+    bool prune = false;                        /* some root element has an interval-prune program: launch the PRUNE kernel variants */
     bool leaf_lights = true;                   /* every light element is a plane / sphere */
     bool count_work = false;                   /* ACN_OPT_COUNT_WORK of the current call */
     uint64_t launches[ 4 ] = { 0, 0, 0, 0 };   /* walk, shade, finalize, hard-ray kernels */
@@ -368,6 +369,113 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
             std::stable_sort( first, first + a.child1, [ & ]( int32_t x, int32_t y ) { return node_cost( x ) < node_cost( y ); } );
         }
     }
+    /* elems[ 2n .. 2n + n_nodes ): per node the offset of its interval-prune program (acn_device.h: prune_run) or -1,
+     * followed by the programs.  Only root elements of compounds that are CSG composites with at least
+     * ACN_PRUNE_MIN nodes get one (small trees are cheaper to walk than to pre-test). */
+    h->dev.prune_base = 2 * scene->n_elems;
+    {
+        size_t min_nodes = 32;
+        if( const char* e = getenv( "ACN_PRUNE_MIN" ) ) min_nodes = ( size_t )atoll( e );
+        elems2.resize( 2 * ( size_t )scene->n_elems );
+        elems2.resize( 2 * ( size_t )scene->n_elems + scene->n_nodes, -1 );
+        std::vector< int32_t > size( scene->n_nodes, -1 );
+        std::function< int32_t( int32_t ) > subtree = [ & ]( int32_t i ) -> int32_t
+        {
+            if( size[ i ] >= 0 ) return size[ i ];
+            const acn_node& a = scene->nodes[ i ];
+            int32_t c = 1;
+            if( a.type == ACN_NEG || a.type == ACN_SCALE ) c += subtree( a.child0 );
+            else if( a.type == ACN_PAIR_INSIDE || a.type == ACN_PAIR_OUTSIDE ) c += subtree( a.child0 ) + subtree( a.child1 );
+            return size[ i ] = c;
+        };
+        std::vector< uint32_t > prog;
+        int max_depth = 0;
+        /* postfix code for node i; returns the interval-stack depth it needs.  The child that needs the deeper
+         * stack is emitted first (the combining ops are symmetric), which keeps balanced trees within the budget. */
+        std::function< int( int32_t, int ) > gen = [ & ]( int32_t i, int depth ) -> int
+        {
+            const acn_node& a = scene->nodes[ i ];
+            int need = 1;
+            switch( a.type )
+            {
+                case ACN_PLANE:    prog.push_back( ACN_PO( ACN_PO_PLANE, i ) ); break;
+                case ACN_SPHERE:   prog.push_back( ACN_PO( ACN_PO_SPHERE, i ) ); break;
+                case ACN_SQUAROID: prog.push_back( ACN_PO( ACN_PO_QUAD, i ) ); break;
+                case ACN_NEG:
+                {
+                    const acn_node& c = scene->nodes[ a.child0 ];
+                    need = gen( a.child0, depth );
+                    bool bare_plane = c.type == ACN_PLANE && !( c.flags & ACN_NODE_HAS_ENVELOPE ) && a.child0 != 0;
+                    prog.push_back( ACN_PO( ACN_PO_NEG, bare_plane ? a.child0 : 0 ) );
+                }
+                break;
+                case ACN_PAIR_INSIDE: case ACN_PAIR_OUTSIDE:
+                {
+                    if( depth >= max_depth ) { prog.push_back( ACN_PO( ACN_PO_ALL, 0 ) ); break; }
+                    /* n-ary view: chains of the same pair type without envelopes in between are one intersection /
+                     * union (the sets H and S do not depend on how the reference's tree is balanced); operands are
+                     * combined one after the other, the one needing the deepest stack first */
+                    std::vector< int32_t > items, todo{ a.child1, a.child0 };
+                    while( !todo.empty() )
+                    {
+                        int32_t c = todo.back(); todo.pop_back();
+                        const acn_node& cn = scene->nodes[ c ];
+                        if( cn.type == a.type && !( cn.flags & ACN_NODE_HAS_ENVELOPE ) ) { todo.push_back( cn.child1 ); todo.push_back( cn.child0 ); }
+                        else items.push_back( c );
+                    }
+                    size_t mark = prog.size();
+                    std::vector< std::pair< int, std::vector< uint32_t > > > code;
+                    for( int32_t c : items )
+                    {
+                        int d = gen( c, depth + 1 );
+                        code.emplace_back( d, std::vector< uint32_t >( prog.begin() + mark, prog.end() ) );
+                        prog.resize( mark );
+                    }
+                    std::stable_sort( code.begin(), code.end(), []( const std::pair< int, std::vector< uint32_t > >& x, const std::pair< int, std::vector< uint32_t > >& y ) { return x.first > y.first; } );
+                    need = code[ 0 ].first;
+                    for( size_t k = 0; k < code.size(); k++ )
+                    {
+                        prog.insert( prog.end(), code[ k ].second.begin(), code[ k ].second.end() );
+                        if( k > 0 )
+                        {
+                            prog.push_back( ACN_PO( a.type == ACN_PAIR_INSIDE ? ACN_PO_AND : ACN_PO_OR, 0 ) );
+                            if( 1 + code[ k ].first > need ) need = 1 + code[ k ].first;
+                        }
+                    }
+                    if( need > ACN_PRUNE_STACK ) { prog.resize( mark ); prog.push_back( ACN_PO( ACN_PO_ALL, 0 ) ); need = 1; }
+                }
+                break;
+                default: prog.push_back( ACN_PO( ACN_PO_ALL, 0 ) ); break;
+            }
+            if( a.flags & ACN_NODE_HAS_ENVELOPE ) prog.push_back( ACN_PO( ACN_PO_ENV, i ) );
+            return need;
+        };
+        const size_t max_ops = 256;
+        for( uint32_t i = 0; i < scene->n_nodes; i++ )
+        {
+            const acn_node& c = scene->nodes[ i ];
+            if( c.type != ACN_COMPOUND ) continue;
+            for( int32_t k = 0; k < c.child1; k++ )
+            {
+                int32_t e = scene->elems[ c.child0 + k ];
+                const acn_node& a = scene->nodes[ e ];
+                if( !( a.type == ACN_PAIR_INSIDE || a.type == ACN_PAIR_OUTSIDE ) ) continue;
+                if( ( size_t )subtree( e ) < min_nodes || elems2[ h->dev.prune_base + e ] >= 0 ) continue;
+                for( max_depth = 12; max_depth >= 1; max_depth-- )   /* the deepest expansion that fits the budget */
+                {
+                    prog.clear();
+                    gen( e, 0 );
+                    if( prog.size() < max_ops ) break;
+                }
+                if( max_depth < 1 ) continue;
+                prog.push_back( ACN_PO( ACN_PO_END, 0 ) );
+                elems2[ h->dev.prune_base + e ] = ( int32_t )elems2.size();
+                h->prune = true;
+                for( uint32_t w : prog ) elems2.push_back( ( int32_t )w );
+            }
+        }
+        elems2.push_back( 0 );
+    }
     HIP_TRY_H( hipMalloc( &h->d_elems, sizeof( int32_t ) * elems2.size() ) );
     HIP_TRY_H( hipMalloc( &h->d_textures, sizeof( acn_texture ) * ( scene->n_textures ? scene->n_textures : 1 ) ) );
     if( scene->n_textures ) HIP_TRY_H( hipMemcpy( h->d_textures, scene->textures, sizeof( acn_texture ) * scene->n_textures, hipMemcpyHostToDevice ) );
@@ -528,11 +636,13 @@ static int launch_shade( acn_scene_handle* h, int cls, uint32_t n_tasks, hipStre
     if( blocks > 256 * 32 ) blocks = 256 * 32;
     int st = stage_begin( h, 1, stream );
     if( st != ACN_OK ) return st;
-#define ACN_LAUNCH_SHADE( C, L ) hipLaunchKernelGGL( ( k_shade< LPT, C, L > ), dim3( ( unsigned )blocks ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ), \
+#define ACN_LAUNCH_SHADE( C, L, P ) hipLaunchKernelGGL( ( k_shade< LPT, C, L, P > ), dim3( ( unsigned )blocks ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ), \
                             ( const DTask* )h->q.tasks, ( const uint32_t* )h->q.idx[ cls ], n_tasks, h->q.children, h->q.child_cap, \
                             h->q.hard_shadow, h->q.hard_path, h->q.hard_cap, h->q.counts, h->d_accum, h->d_counters )
-    if( h->count_work ) { if( h->leaf_lights ) ACN_LAUNCH_SHADE( true, true ); else ACN_LAUNCH_SHADE( true, false ); }
-    else                { if( h->leaf_lights ) ACN_LAUNCH_SHADE( false, true ); else ACN_LAUNCH_SHADE( false, false ); }
+    /* the prune-program variants exist for the uninstrumented kernels only; count_work runs the plain ones */
+    if( h->count_work )   { if( h->leaf_lights ) ACN_LAUNCH_SHADE( true, true, false ); else ACN_LAUNCH_SHADE( true, false, false ); }
+    else if( h->prune )   { if( h->leaf_lights ) ACN_LAUNCH_SHADE( false, true, true ); else ACN_LAUNCH_SHADE( false, false, true ); }
+    else                  { if( h->leaf_lights ) ACN_LAUNCH_SHADE( false, true, false ); else ACN_LAUNCH_SHADE( false, false, false ); }
 #undef ACN_LAUNCH_SHADE
     HIP_TRY( hipGetLastError() );
     return stage_end( h, stream );
@@ -558,11 +668,12 @@ static int walk_passes( acn_scene_handle* h, uint32_t n_in, int* cur, hipStream_
         int in = *cur, out = 1 - in;
         HIP_TRY( hipMemsetAsync( h->q.counts + QC_RAYS, 0, sizeof( uint32_t ), stream ) );
         if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
-#define ACN_LAUNCH_TRACE( P, C, L, N, ... ) hipLaunchKernelGGL( ( k_trace_rays< P, C, L > ), dim3( ( ( N ) + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + h->lds_stack_bytes, stream, \
+#define ACN_LAUNCH_TRACE( P, C, L, R, N, ... ) hipLaunchKernelGGL( ( k_trace_rays< P, C, L, R > ), dim3( ( ( N ) + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + h->lds_stack_bytes, stream, \
             ACN_SCENE_ARGS( h ), __VA_ARGS__, h->d_accum, h->d_counters )
 #define ACN_DISPATCH_TRACE( P, N, ... ) do { \
-            if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_TRACE( P, true, true, N, __VA_ARGS__ ); else ACN_LAUNCH_TRACE( P, true, false, N, __VA_ARGS__ ); } \
-            else                { if( h->lds_bytes ) ACN_LAUNCH_TRACE( P, false, true, N, __VA_ARGS__ ); else ACN_LAUNCH_TRACE( P, false, false, N, __VA_ARGS__ ); } } while( 0 )
+            if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_TRACE( P, true, true, false, N, __VA_ARGS__ ); else ACN_LAUNCH_TRACE( P, true, false, false, N, __VA_ARGS__ ); } \
+            else if( h->prune ) { if( h->lds_bytes ) ACN_LAUNCH_TRACE( P, false, true, true, N, __VA_ARGS__ ); else ACN_LAUNCH_TRACE( P, false, false, true, N, __VA_ARGS__ ); } \
+            else                { if( h->lds_bytes ) ACN_LAUNCH_TRACE( P, false, true, false, N, __VA_ARGS__ ); else ACN_LAUNCH_TRACE( P, false, false, false, N, __VA_ARGS__ ); } } while( 0 )
         ACN_DISPATCH_TRACE( false, n_in, ACN_WALK_QUEUE_ARGS( h, out ), ( const RayTask* )h->rays[ in ], ( const double* )nullptr, ( size_t )0, 0u, n_in );
         HIP_TRY( hipGetLastError() );
         if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
@@ -616,20 +727,22 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
             if( n_hs )
             {
                 if( ( st = stage_begin( h, 3, stream ) ) != ACN_OK ) return st;
-#define ACN_LAUNCH_HS( C, L ) hipLaunchKernelGGL( ( k_hard_shadow< C, L > ), dim3( ( n_hs + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + h->lds_stack_bytes, stream, ACN_SCENE_ARGS( h ), \
+#define ACN_LAUNCH_HS( C, L, P ) hipLaunchKernelGGL( ( k_hard_shadow< C, L, P > ), dim3( ( n_hs + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + h->lds_stack_bytes, stream, ACN_SCENE_ARGS( h ), \
                     ( const HardShadow* )h->q.hard_shadow, n_hs, h->q.counts, h->d_accum, h->d_counters )
-                if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_HS( true, true ); else ACN_LAUNCH_HS( true, false ); }
-                else                { if( h->lds_bytes ) ACN_LAUNCH_HS( false, true ); else ACN_LAUNCH_HS( false, false ); }
+                if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_HS( true, true, false ); else ACN_LAUNCH_HS( true, false, false ); }
+                else if( h->prune ) { if( h->lds_bytes ) ACN_LAUNCH_HS( false, true, true ); else ACN_LAUNCH_HS( false, false, true ); }
+                else                { if( h->lds_bytes ) ACN_LAUNCH_HS( false, true, false ); else ACN_LAUNCH_HS( false, false, false ); }
                 HIP_TRY( hipGetLastError() );
                 if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
             }
             if( n_hp )
             {
                 if( ( st = stage_begin( h, 3, stream ) ) != ACN_OK ) return st;
-#define ACN_LAUNCH_HP( C, L ) hipLaunchKernelGGL( ( k_hard_path< C, L > ), dim3( ( n_hp + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + h->lds_stack_bytes, stream, ACN_SCENE_ARGS( h ), \
+#define ACN_LAUNCH_HP( C, L, P ) hipLaunchKernelGGL( ( k_hard_path< C, L, P > ), dim3( ( n_hp + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + h->lds_stack_bytes, stream, ACN_SCENE_ARGS( h ), \
                     ( const HardPath* )h->q.hard_path, n_hp, h->q.children, h->q.child_cap, h->q.counts, h->d_accum, h->d_counters )
-                if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_HP( true, true ); else ACN_LAUNCH_HP( true, false ); }
-                else                { if( h->lds_bytes ) ACN_LAUNCH_HP( false, true ); else ACN_LAUNCH_HP( false, false ); }
+                if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_HP( true, true, false ); else ACN_LAUNCH_HP( true, false, false ); }
+                else if( h->prune ) { if( h->lds_bytes ) ACN_LAUNCH_HP( false, true, true ); else ACN_LAUNCH_HP( false, false, true ); }
+                else                { if( h->lds_bytes ) ACN_LAUNCH_HP( false, true, false ); else ACN_LAUNCH_HP( false, false, false ); }
                 HIP_TRY( hipGetLastError() );
                 if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
                 if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
