@@ -559,6 +559,109 @@ template< class NP > DEV int distance_side( NP o, V3 pos )   /* objects.c:961-96
     return sdf_eval( o, p ) > 0 ? 1 : -1;
 }
 
+template< class NP > DEV V3 roughness_normal( NP hdr, V3 n, V3 hit_pos )   /* objects.c:267-282 */
+{
+    uint64_t rv = v_random_seed( hit_pos, 1246 );
+    double f;
+    f = f3_rnd0( &rv ) * 0.99;
+    n.x += hdr->surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
+    f = f3_rnd0( &rv ) * 0.99;
+    n.y += hdr->surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
+    f = f3_rnd0( &rv ) * 0.99;
+    n.z += hdr->surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
+    return v_of_length( n, 1.0 );
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* Leaf pairs.  Most composites at the bottom of a CSG tree combine two simple operands -- a plane, sphere or squaroid,
+ * possibly complemented (slabs, lenses, capped cylinders; 5 of the wine glass's 9 pairs, the whole liquid).  The upload
+ * step marks such pairs (ACN_GFLAG_LEAF_PAIR) and both machines evaluate them in line: the same sequence of child
+ * evaluations, side tests and walk steps as the general frames (objects.c:1052-1094 / 1209-1251, 1096-1099 / 1253-1256),
+ * without frame, stack or nested loops. */
+#define ACN_GFLAG_LEAF_PAIR 0x100u      /* device-only bit of GNode.flags */
+
+template< class NP > DEV int simple_leaf_side( NP g, V3 pos )
+{
+    int type = g->type;
+    if( type == ACN_PLANE )  return v_sub_mlv( pos, ld3( g->pos ), ld3( g->rax + 6 ) ) > 0 ? 1 : -1;
+    if( type == ACN_SPHERE ) return sphere_observer_side( ld3( g->pos ), g->prm[ 0 ], pos );
+    return squaroid_side( g, pos );
+}
+
+/* obj_side of an operand of a leaf pair: a simple leaf or NEG( simple leaf ) */
+template< class SR, class CT > DEV int operand_side( SR sc, int c, V3 pos, CT* cnt )
+{
+    auto cn = &sc.nodes[ c ];
+    cnt->inc( CNT_SIDE );
+    if( node_has_env( cn ) && env_side( cn, pos ) == 1 ) return 1;
+    if( cn->type != ACN_NEG ) return simple_leaf_side( cn, pos );
+    auto g = &sc.nodes[ cn->child0 ];
+    cnt->inc( CNT_SIDE );
+    int r = ( node_has_env( g ) && env_side( g, pos ) == 1 ) ? 1 : simple_leaf_side( g, pos );
+    return -r;
+}
+
+template< class NP > DEV double simple_leaf_hit( NP g, V3 rp, V3 rd, bool want_nor, V3* nor )
+{
+    int type = g->type;
+    double a;
+    if( type == ACN_PLANE )       a = plane_ray_hit( ld3( g->pos ), ld3( g->rax + 6 ), rp, rd, want_nor, nor );
+    else if( type == ACN_SPHERE ) a = sphere_ray_hit( ld3( g->pos ), g->prm[ 0 ], rp, rd, want_nor, nor );
+    else                          a = squaroid_ray_hit( g, rp, rd, want_nor, nor );
+    if( want_nor && a < F3_INF && g->surface_roughness > 0 ) *nor = roughness_normal( g, *nor, ray_pos( rp, rd, a ) );
+    return a;
+}
+
+/* obj_ray_hit of an operand of a leaf pair */
+template< class SR, class CT > DEV double operand_hit( SR sc, int c, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
+{
+    auto cn = &sc.nodes[ c ];
+    cnt->inc( CNT_OBJ_HIT );
+    if( node_has_env( cn ) && !env_ray_hits( cn, rp, rd ) ) return F3_INF;
+    if( cn->type != ACN_NEG ) return simple_leaf_hit( cn, rp, rd, want_nor, nor );
+    auto g = &sc.nodes[ cn->child0 ];
+    cnt->inc( CNT_OBJ_HIT );
+    double a = ( node_has_env( g ) && !env_ray_hits( g, rp, rd ) ) ? F3_INF : simple_leaf_hit( g, rp, rd, want_nor, nor );
+    if( a < F3_INF && want_nor )
+    {
+        *nor = v_neg( *nor );                                                                  /* objects.c:1329-1339 */
+        if( cn->surface_roughness > 0 ) *nor = roughness_normal( cn, *nor, ray_pos( rp, rd, a ) );
+    }
+    return a;
+}
+
+template< class SR, class NP, class CT > DEV int leaf_pair_side( SR sc, NP n, V3 pos, CT* cnt )
+{
+    int want = ( n->type == ACN_PAIR_INSIDE ) ? -1 : 1;
+    if( operand_side( sc, n->child0, pos, cnt ) != want ) return -want;
+    return operand_side( sc, n->child1, pos, cnt ) == want ? want : -want;
+}
+
+/* the pair's hit without its own envelope test and roughness (the caller does both, as for any node) */
+template< class SR, class NP, class CT > DEV double leaf_pair_hit( SR sc, NP n, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
+{
+    int want = ( n->type == ACN_PAIR_INSIDE ) ? -1 : 1;
+    int c0 = n->child0, c1 = n->child1;
+    V3 n1 = mk( 0, 0, 0 ), n2 = mk( 0, 0, 0 );
+    double a1 = operand_hit( sc, c0, rp, rd, want_nor, &n1, cnt );
+    double a2 = operand_hit( sc, c1, rp, rd, want_nor, &n2, cnt );
+    if( a1 < a2 && operand_side( sc, c1, ray_pos( rp, rd, a1 ), cnt ) == want ) { *nor = n1; return a1; }
+    if( a2 >= F3_INF ) return F3_INF;
+    if( operand_side( sc, c0, ray_pos( rp, rd, a2 ), cnt ) == want ) { *nor = n2; return a2; }
+    double offs = a2;
+    bool swapped = false;
+    for( ;; )
+    {
+        V3 walk_p = ray_pos( rp, rd, offs );
+        double a = operand_hit( sc, swapped ? c1 : c0, walk_p, rd, want_nor, &n1, cnt );
+        if( a >= F3_INF ) return F3_INF;
+        if( operand_side( sc, swapped ? c0 : c1, ray_pos( walk_p, rd, a ), cnt ) == want ) { *nor = n1; return offs + a; }
+        offs += a + 2 * F3_EPS;
+        if( !( offs < F3_INF ) ) return F3_INF;
+        swapped = !swapped;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* CSG machines.  obj_side and obj_ray_hit recurse through pair / neg / scale nodes in the reference; here they are
  * per-lane state machines.  The innermost composite's frame lives in registers; enclosing frames sit on a per-lane
@@ -606,6 +709,10 @@ DEV_SIDE int obj_side_dev( SR sc, int root, V3 pos, CT* cnt )
                 case ACN_SQUAROID: r = squaroid_side( n, pos ); break;
                 default:           r = distance_side( n, pos ); cnt->inc( CNT_SDF_EVAL ); break;
             }
+        }
+        else if( n->flags & ACN_GFLAG_LEAF_PAIR )
+        {
+            r = leaf_pair_side( sc, n, pos, cnt );
         }
         else if( depth >= ACN_CSG_MAX_DEPTH )
         {
@@ -670,18 +777,6 @@ DEV_SIDE int obj_side_dev( SR sc, int root, V3 pos, CT* cnt )
 #define ACN_HW_NODE( w )     ( ( int )( ( w ) >> 4 ) )
 #define ACN_HW_PACK( node, pc, swapped, inherit ) ( ( ( uint32_t )( node ) << 4 ) | ( ( uint32_t )( inherit ) << 3 ) | ( ( uint32_t )( swapped ) << 2 ) | ( uint32_t )( pc ) )
 
-template< class NP > DEV V3 roughness_normal( NP hdr, V3 n, V3 hit_pos )   /* objects.c:267-282 */
-{
-    uint64_t rv = v_random_seed( hit_pos, 1246 );
-    double f;
-    f = f3_rnd0( &rv ) * 0.99;
-    n.x += hdr->surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
-    f = f3_rnd0( &rv ) * 0.99;
-    n.y += hdr->surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
-    f = f3_rnd0( &rv ) * 0.99;
-    n.z += hdr->surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
-    return v_of_length( n, 1.0 );
-}
 
 template< class SR, class CT >
 DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3* out_nor, CT* cnt )
@@ -722,6 +817,11 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
                 case ACN_SQUAROID: ret_a = squaroid_ray_hit( n, rp, rd, want_nor, &ret_n ); break;
                 default:           ret_a = distance_ray_hit( n, rp, rd, want_nor, &ret_n, cnt ); break;
             }
+            if( want_nor && ret_a < F3_INF && n->surface_roughness > 0 ) ret_n = roughness_normal( n, ret_n, ray_pos( rp, rd, ret_a ) );
+        }
+        else if( n->flags & ACN_GFLAG_LEAF_PAIR )
+        {
+            ret_a = leaf_pair_hit( sc, n, rp, rd, want_nor, &ret_n, cnt );
             if( want_nor && ret_a < F3_INF && n->surface_roughness > 0 ) ret_n = roughness_normal( n, ret_n, ray_pos( rp, rd, ret_a ) );
         }
         else if( depth >= ACN_CSG_MAX_DEPTH )

@@ -319,6 +319,16 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
         GNode& g = nodes[ i ];
         memset( &g, 0, sizeof( g ) );
         g.type = a.type; g.flags = a.flags; g.child0 = a.child0; g.child1 = a.child1;
+        if( ( a.type == ACN_PAIR_INSIDE || a.type == ACN_PAIR_OUTSIDE ) && !getenv( "ACN_NO_LEAF_PAIRS" ) )
+        {
+            auto simple = [ & ]( int32_t c )
+            {
+                const acn_node* x = &scene->nodes[ c ];
+                if( x->type == ACN_NEG ) x = &scene->nodes[ x->child0 ];
+                return x->type == ACN_PLANE || x->type == ACN_SPHERE || x->type == ACN_SQUAROID;
+            };
+            if( simple( a.child0 ) && simple( a.child1 ) ) g.flags |= ACN_GFLAG_LEAF_PAIR;
+        }
         memcpy( g.prm, a.prm, sizeof( g.prm ) );
         memcpy( g.pos, a.pos, sizeof( g.pos ) );
         memcpy( g.env_pos, a.env_pos, sizeof( g.env_pos ) );
