@@ -1333,6 +1333,22 @@ DEV double leaf_element_hit( NP n, int type, V3 rp, V3 rd, V3* nor, CT* cnt )
     return a;
 }
 
+/* a ROOT element that is a leaf pair: obj_ray_hit (objects.c:261-284) in line, no machine, no deferral */
+template< bool NOR, class SC, class NP, class CT >
+DEV double leaf_pair_element_hit( const SC& sc, NP n, V3 rp, V3 rd, V3* nor, CT* cnt )
+{
+    cnt->inc( CNT_OBJ_HIT );
+    if( node_has_env( n ) && !env_ray_hits( n, rp, rd ) ) return F3_INF;
+    V3 nn = mk( 0, 0, 0 );
+    double a = leaf_pair_hit( sref( sc ), n, rp, rd, NOR, &nn, cnt );
+    if( NOR && a < F3_INF )
+    {
+        if( n->surface_roughness > 0 ) nn = roughness_normal( n, nn, ray_pos( rp, rd, a ) );
+        *nor = nn;
+    }
+    return a;
+}
+
 /* 0: not occluded, 1: occluded, 2: undecided (hard) */
 template< class SC, class CT >
 DEV int root_occluded_fast( const SC& sc, int cmp, V3 rp, V3 rd, double limit, CT* cnt )
@@ -1349,6 +1365,11 @@ DEV int root_occluded_fast( const SC& sc, int cmp, V3 rp, V3 rd, double limit, C
         if( is_fast_type( type ) )
         {
             double a = leaf_element_hit< false >( n, type, rp, rd, nullptr, cnt );
+            if( a <= limit ) return 1;
+        }
+        else if( n->flags & ACN_GFLAG_LEAF_PAIR )
+        {
+            double a = leaf_pair_element_hit< false >( sc, n, rp, rd, nullptr, cnt );
             if( a <= limit ) return 1;
         }
         else if( type == ACN_COMPOUND || type == ACN_DISTANCE ? ( !node_has_env( n ) || env_ray_hits( n, rp, rd ) )
@@ -1375,14 +1396,15 @@ DEV double root_trans_hit_fast( const SC& sc, int cmp, V3 rp, V3 rd, Trans* tran
         int element = __builtin_amdgcn_readfirstlane( sc.elems[ first + i ] );
         auto n = &sc.nodes[ element ];
         int type = n->type;
-        if( !is_fast_type( type ) )
+        if( !is_fast_type( type ) && !( n->flags & ACN_GFLAG_LEAF_PAIR ) )
         {
             if( type == ACN_COMPOUND || type == ACN_DISTANCE ? ( !node_has_env( n ) || env_ray_hits( n, rp, rd ) )
                                                              : !( surely_outside< ACN_PRUNE_DEPTH >( sc, element, rp, rd ) || ACN_FAST_PRUNE( sc, element, rp, rd, F3_INF ) ) ) h = true;
             continue;
         }
         V3 nor = mk( 0, 0, 0 );
-        double a = leaf_element_hit< true >( n, type, rp, rd, &nor, cnt );
+        double a = is_fast_type( type ) ? leaf_element_hit< true >( n, type, rp, rd, &nor, cnt )
+                                        : leaf_pair_element_hit< true >( sc, n, rp, rd, &nor, cnt );
         if( a < F3_INF )
         {
             if( a < min_a - F3_EPS )
