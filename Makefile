@@ -16,9 +16,15 @@ host: $(LIBDIR)/libactinon_host.so
 oracle: oracle/libacn_oracle.so oracle/libacn_oracle_libm.so
 cli: actinon_amd/bin/actinon_hip
 
-$(LIBDIR)/libactinon_hip.so: actinon_amd/csrc/actinon_hip.hip $(wildcard actinon_amd/csrc/*.h) include/actinon_hip.h
+# one object per kernel family: `make -j` compiles them side by side (acn_launch.h)
+HIP_UNITS := actinon_hip k_shade_64 k_shade_16 k_shade_4 k_shade_1 k_trace k_hard
+HIP_OBJS  := $(addprefix build/,$(addsuffix .o,$(HIP_UNITS)))
+build/%.o: actinon_amd/csrc/%.hip $(wildcard actinon_amd/csrc/*.h) include/actinon_hip.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(LIBDIR)/libactinon_hip.so: $(HIP_OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ actinon_amd/csrc/actinon_hip.hip
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS)
 
 $(LIBDIR)/libactinon_host.so: actinon_amd/host/acn_scene.c actinon_amd/host/acn_driver.c actinon_amd/host/acn_scenes.c actinon_amd/host/acn_interp.c include/acn_scene.h include/acn_interp.h include/actinon_hip.h $(LIBDIR)/libactinon_hip.so
 	$(CC) $(CFLAGS) -shared -o $@ actinon_amd/host/acn_scene.c actinon_amd/host/acn_driver.c actinon_amd/host/acn_scenes.c actinon_amd/host/acn_interp.c -L$(LIBDIR) -lactinon_hip -lm -Wl,-rpath,'$$ORIGIN'
@@ -34,6 +40,6 @@ oracle/libacn_oracle_libm.so: oracle/acn_oracle.c oracle/acn_oracle.h include/ac
 	$(CC) $(CFLAGS) -march=native -DACN_ORACLE_LIBM -Ioracle -shared -o $@ oracle/acn_oracle.c -lm -lpthread
 
 clean:
-	rm -f $(LIBDIR)/*.so oracle/*.so actinon_amd/bin/actinon_hip
+	rm -rf build; rm -f $(LIBDIR)/*.so oracle/*.so actinon_amd/bin/actinon_hip
 
 .PHONY: all hip host oracle cli clean

@@ -1014,7 +1014,13 @@ DEVN double compound_ray_hit_dev( SR sc, int cmp, V3 rp, V3 rd, bool want_nor, V
             continue;
         }
         V3 nor;
-        double a = obj_ray_hit_dev( sc, element, rp, rd, want_nor, &nor, cnt );
+        double a;
+        if( e->type >= ACN_PLANE && e->type <= ACN_SQUAROID )   /* a simple leaf (every element of many_spheres): no need for the machine */
+        {
+            cnt->inc( CNT_OBJ_HIT );
+            a = ( node_has_env( e ) && !env_ray_hits( e, rp, rd ) ) ? F3_INF : simple_leaf_hit( e, rp, rd, want_nor, &nor );
+        }
+        else a = obj_ray_hit_dev( sc, element, rp, rd, want_nor, &nor, cnt );
         if( a < min_a )
         {
             min_a = a;

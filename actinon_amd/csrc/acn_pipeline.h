@@ -725,19 +725,5 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
     wave_add_counters( counters, cnt );
 }
 
-/* fixed point -> f64 (+ optional cl_s_sat) for positions [ base, base + n ) */
-__global__ void k_finalize( const unsigned long long* __restrict__ accum, uint32_t n, double gamma, int linear,
-                            double* __restrict__ out_rgb )
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if( i >= n ) return;
-    V3 c = mk( ( double )( long long )accum[ ( size_t )i * 3 + 0 ] * ACN_FIX_INV,
-               ( double )( long long )accum[ ( size_t )i * 3 + 1 ] * ACN_FIX_INV,
-               ( double )( long long )accum[ ( size_t )i * 3 + 2 ] * ACN_FIX_INV );
-    if( !linear ) c = cl_sat( c, gamma );
-    out_rgb[ ( size_t )i * 3 + 0 ] = c.x;
-    out_rgb[ ( size_t )i * 3 + 1 ] = c.y;
-    out_rgb[ ( size_t )i * 3 + 2 ] = c.z;
-}
 
 #endif /* ACN_PIPELINE_H */

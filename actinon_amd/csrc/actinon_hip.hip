@@ -9,7 +9,7 @@
 #include <functional>
 #include <algorithm>
 
-#include "acn_pipeline.h"
+#include "acn_launch.h"
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* error plumbing */
@@ -67,6 +67,21 @@ __global__ void k_camera_setup( DevScene sc, M3* out_rot, double* out_unit_f )
     V3 rx = v_mlx( ry, rz );
     M3 r; r.x = rx; r.y = ry; r.z = rz;
     *out_rot = m_transposed( r );
+}
+
+/* fixed point -> f64 (+ optional cl_s_sat) for positions [ base, base + n ) */
+__global__ void k_finalize( const unsigned long long* __restrict__ accum, uint32_t n, double gamma, int linear,
+                            double* __restrict__ out_rgb )
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n ) return;
+    V3 c = mk( ( double )( long long )accum[ ( size_t )i * 3 + 0 ] * ACN_FIX_INV,
+               ( double )( long long )accum[ ( size_t )i * 3 + 1 ] * ACN_FIX_INV,
+               ( double )( long long )accum[ ( size_t )i * 3 + 2 ] * ACN_FIX_INV );
+    if( !linear ) c = cl_sat( c, gamma );
+    out_rgb[ ( size_t )i * 3 + 0 ] = c.x;
+    out_rgb[ ( size_t )i * 3 + 1 ] = c.y;
+    out_rgb[ ( size_t )i * 3 + 2 ] = c.z;
 }
 
 /* cl_s_sat + cps_from_cl after the (cross-GPU) accumulation */
@@ -636,6 +651,27 @@ static int read_counts( acn_scene_handle* h, hipStream_t stream )
     return ACN_OK;
 }
 
+static SceneArgs scene_args( const acn_scene_handle* h )
+{
+    SceneArgs s;
+    s.dev = h->dev; s.nodes = h->d_nodes; s.mats = h->d_mats; s.elems = h->d_elems; s.textures = h->d_textures;
+    return s;
+}
+static KernelFlags kernel_flags( const acn_scene_handle* h )
+{
+    KernelFlags f;
+    f.count = h->count_work; f.leaf_lights = h->leaf_lights; f.lds_nodes = h->lds_bytes != 0; f.prune = h->prune;
+    return f;
+}
+static WalkQueueArgs walk_queue_args( const acn_scene_handle* h, int out )
+{
+    WalkQueueArgs q;
+    q.tasks = h->q.tasks; for( int k = 0; k < 4; k++ ) q.idx[ k ] = h->q.idx[ k ];
+    q.counts = h->q.counts; q.task_cap = h->q.task_cap; q.rays_out = h->rays[ out ]; q.ray_cap = h->q.ray_cap;
+    return q;
+}
+static size_t machine_lds_bytes( const acn_scene_handle* h ) { return h->lds_bytes + h->lds_stack_bytes; }
+
 template< int LPT >
 static int launch_shade( acn_scene_handle* h, int cls, uint32_t n_tasks, hipStream_t stream )
 {
@@ -646,20 +682,12 @@ static int launch_shade( acn_scene_handle* h, int cls, uint32_t n_tasks, hipStre
     if( blocks > 256 * 32 ) blocks = 256 * 32;
     int st = stage_begin( h, 1, stream );
     if( st != ACN_OK ) return st;
-#define ACN_LAUNCH_SHADE( C, L, P ) hipLaunchKernelGGL( ( k_shade< LPT, C, L, P > ), dim3( ( unsigned )blocks ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ), \
-                            ( const DTask* )h->q.tasks, ( const uint32_t* )h->q.idx[ cls ], n_tasks, h->q.children, h->q.child_cap, \
-                            h->q.hard_shadow, h->q.hard_path, h->q.hard_cap, h->q.counts, h->d_accum, h->d_counters )
-    /* the prune-program variants exist for the uninstrumented kernels only; count_work runs the plain ones */
-    if( h->count_work )   { if( h->leaf_lights ) ACN_LAUNCH_SHADE( true, true, false ); else ACN_LAUNCH_SHADE( true, false, false ); }
-    else if( h->prune )   { if( h->leaf_lights ) ACN_LAUNCH_SHADE( false, true, true ); else ACN_LAUNCH_SHADE( false, false, true ); }
-    else                  { if( h->leaf_lights ) ACN_LAUNCH_SHADE( false, true, false ); else ACN_LAUNCH_SHADE( false, false, false ); }
-#undef ACN_LAUNCH_SHADE
+    auto fn = LPT == 64 ? acn_launch_shade64 : LPT == 16 ? acn_launch_shade16 : LPT == 4 ? acn_launch_shade4 : acn_launch_shade1;
+    fn( kernel_flags( h ), ( unsigned )blocks, stream, scene_args( h ), ( const DTask* )h->q.tasks, ( const uint32_t* )h->q.idx[ cls ], n_tasks,
+        h->q.children, h->q.child_cap, h->q.hard_shadow, h->q.hard_path, h->q.hard_cap, h->q.counts, h->d_accum, h->d_counters );
     HIP_TRY( hipGetLastError() );
     return stage_end( h, stream );
 }
-
-#define ACN_WALK_QUEUE_ARGS( h, out ) ( h )->q.tasks, ( h )->q.idx[ 0 ], ( h )->q.idx[ 1 ], ( h )->q.idx[ 2 ], ( h )->q.idx[ 3 ], ( h )->q.counts, \
-    ( h )->q.task_cap, ( h )->rays[ out ], ( h )->q.ray_cap
 
 static int check_flags( acn_scene_handle* h, int* overflow )
 {
@@ -678,13 +706,8 @@ static int walk_passes( acn_scene_handle* h, uint32_t n_in, int* cur, hipStream_
         int in = *cur, out = 1 - in;
         HIP_TRY( hipMemsetAsync( h->q.counts + QC_RAYS, 0, sizeof( uint32_t ), stream ) );
         if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
-#define ACN_LAUNCH_TRACE( P, C, L, R, N, ... ) hipLaunchKernelGGL( ( k_trace_rays< P, C, L, R > ), dim3( ( ( N ) + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + h->lds_stack_bytes, stream, \
-            ACN_SCENE_ARGS( h ), __VA_ARGS__, h->d_accum, h->d_counters )
-#define ACN_DISPATCH_TRACE( P, N, ... ) do { \
-            if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_TRACE( P, true, true, false, N, __VA_ARGS__ ); else ACN_LAUNCH_TRACE( P, true, false, false, N, __VA_ARGS__ ); } \
-            else if( h->prune ) { if( h->lds_bytes ) ACN_LAUNCH_TRACE( P, false, true, true, N, __VA_ARGS__ ); else ACN_LAUNCH_TRACE( P, false, false, true, N, __VA_ARGS__ ); } \
-            else                { if( h->lds_bytes ) ACN_LAUNCH_TRACE( P, false, true, false, N, __VA_ARGS__ ); else ACN_LAUNCH_TRACE( P, false, false, false, N, __VA_ARGS__ ); } } while( 0 )
-        ACN_DISPATCH_TRACE( false, n_in, ACN_WALK_QUEUE_ARGS( h, out ), ( const RayTask* )h->rays[ in ], ( const double* )nullptr, ( size_t )0, 0u, n_in );
+        acn_launch_trace( false, kernel_flags( h ), n_in, machine_lds_bytes( h ), stream, scene_args( h ), walk_queue_args( h, out ),
+                          ( const RayTask* )h->rays[ in ], nullptr, 0, 0u, h->d_accum, h->d_counters );
         HIP_TRY( hipGetLastError() );
         if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
         if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
@@ -706,7 +729,8 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
     HIP_TRY( hipMemsetAsync( h->q.counts, 0, sizeof( uint32_t ) * QC_N, stream ) );
     /* level 0, pass 0: the camera rays */
     if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
-    ACN_DISPATCH_TRACE( true, cnt, ACN_WALK_QUEUE_ARGS( h, cur ), ( const RayTask* )nullptr, d_pos_xy, first_pixel, base, cnt );
+    acn_launch_trace( true, kernel_flags( h ), cnt, machine_lds_bytes( h ), stream, scene_args( h ), walk_queue_args( h, cur ),
+                      nullptr, d_pos_xy, first_pixel, base, h->d_accum, h->d_counters );
     HIP_TRY( hipGetLastError() );
     if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
     if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
@@ -737,22 +761,16 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
             if( n_hs )
             {
                 if( ( st = stage_begin( h, 3, stream ) ) != ACN_OK ) return st;
-#define ACN_LAUNCH_HS( C, L, P ) hipLaunchKernelGGL( ( k_hard_shadow< C, L, P > ), dim3( ( n_hs + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + h->lds_stack_bytes, stream, ACN_SCENE_ARGS( h ), \
-                    ( const HardShadow* )h->q.hard_shadow, n_hs, h->q.counts, h->d_accum, h->d_counters )
-                if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_HS( true, true, false ); else ACN_LAUNCH_HS( true, false, false ); }
-                else if( h->prune ) { if( h->lds_bytes ) ACN_LAUNCH_HS( false, true, true ); else ACN_LAUNCH_HS( false, false, true ); }
-                else                { if( h->lds_bytes ) ACN_LAUNCH_HS( false, true, false ); else ACN_LAUNCH_HS( false, false, false ); }
+                acn_launch_hard_shadow( kernel_flags( h ), n_hs, machine_lds_bytes( h ), stream, scene_args( h ),
+                                        ( const HardShadow* )h->q.hard_shadow, h->q.counts, h->d_accum, h->d_counters );
                 HIP_TRY( hipGetLastError() );
                 if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
             }
             if( n_hp )
             {
                 if( ( st = stage_begin( h, 3, stream ) ) != ACN_OK ) return st;
-#define ACN_LAUNCH_HP( C, L, P ) hipLaunchKernelGGL( ( k_hard_path< C, L, P > ), dim3( ( n_hp + 255 ) / 256 ), dim3( 256 ), ( ( L ) ? h->lds_bytes : 0 ) + h->lds_stack_bytes, stream, ACN_SCENE_ARGS( h ), \
-                    ( const HardPath* )h->q.hard_path, n_hp, h->q.children, h->q.child_cap, h->q.counts, h->d_accum, h->d_counters )
-                if( h->count_work ) { if( h->lds_bytes ) ACN_LAUNCH_HP( true, true, false ); else ACN_LAUNCH_HP( true, false, false ); }
-                else if( h->prune ) { if( h->lds_bytes ) ACN_LAUNCH_HP( false, true, true ); else ACN_LAUNCH_HP( false, false, true ); }
-                else                { if( h->lds_bytes ) ACN_LAUNCH_HP( false, true, false ); else ACN_LAUNCH_HP( false, false, false ); }
+                acn_launch_hard_path( kernel_flags( h ), n_hp, machine_lds_bytes( h ), stream, scene_args( h ),
+                                      ( const HardPath* )h->q.hard_path, h->q.children, h->q.child_cap, h->q.counts, h->d_accum, h->d_counters );
                 HIP_TRY( hipGetLastError() );
                 if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
                 if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
@@ -766,12 +784,8 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
         HIP_TRY( hipMemsetAsync( h->q.counts, 0, sizeof( uint32_t ) * QC_CHILDREN, stream ) );
         HIP_TRY( hipMemsetAsync( h->q.counts + QC_RAYS, 0, sizeof( uint32_t ), stream ) );
         if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
-        if( h->count_work )
-            hipLaunchKernelGGL( k_shade_hits< true >, dim3( ( n_children + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                                ACN_WALK_QUEUE_ARGS( h, cur ), ( const HitRec* )h->q.children, n_children, h->d_accum, h->d_counters );
-        else
-            hipLaunchKernelGGL( k_shade_hits< false >, dim3( ( n_children + 255 ) / 256 ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS( h ),
-                                ACN_WALK_QUEUE_ARGS( h, cur ), ( const HitRec* )h->q.children, n_children, h->d_accum, h->d_counters );
+        acn_launch_shade_hits( h->count_work, n_children, stream, scene_args( h ), walk_queue_args( h, cur ),
+                               ( const HitRec* )h->q.children, h->d_accum, h->d_counters );
         HIP_TRY( hipGetLastError() );
         if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
         if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;

@@ -23,7 +23,7 @@ def built_libraries():
     need = ["actinon_amd/lib/libactinon_hip.so", "actinon_amd/lib/libactinon_host.so", "oracle/libacn_oracle.so",
             "oracle/libacn_oracle_libm.so"]
     if not all(_have(p) for p in need):
-        subprocess.check_call(["make", "-C", ROOT, "all"])
+        subprocess.check_call(["make", "-C", ROOT, "-j", str(min(8, os.cpu_count() or 1)), "all"])
     yield
 
 
