@@ -47,7 +47,7 @@ struct acn_scene_handle
     bool leaf_lights = true;                   /* every light element is a plane / sphere */
     bool count_work = false;                   /* ACN_OPT_COUNT_WORK of the current call */
     uint64_t launches[ 4 ] = { 0, 0, 0, 0 };   /* walk, shade, finalize, hard-ray kernels */
-    uint64_t hard_rays = 0, walk_passes = 0;
+    uint64_t hard_rays = 0, walk_passes = 0, walk_rays = 0, shade_hit_recs = 0;
     size_t good_chunk = 0;
     uint64_t chunks = 0, retries = 0, levels = 0;
     uint64_t peak_tasks = 0, peak_children = 0;
@@ -706,6 +706,7 @@ static int walk_passes( acn_scene_handle* h, uint32_t n_in, int* cur, hipStream_
         int in = *cur, out = 1 - in;
         HIP_TRY( hipMemsetAsync( h->q.counts + QC_RAYS, 0, sizeof( uint32_t ), stream ) );
         if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
+        h->walk_rays += n_in;
         acn_launch_trace( false, kernel_flags( h ), n_in, machine_lds_bytes( h ), stream, scene_args( h ), walk_queue_args( h, out ),
                           ( const RayTask* )h->rays[ in ], nullptr, 0, 0u, h->d_accum, h->d_counters );
         HIP_TRY( hipGetLastError() );
@@ -729,6 +730,7 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
     HIP_TRY( hipMemsetAsync( h->q.counts, 0, sizeof( uint32_t ) * QC_N, stream ) );
     /* level 0, pass 0: the camera rays */
     if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
+    h->walk_rays += cnt;
     acn_launch_trace( true, kernel_flags( h ), cnt, machine_lds_bytes( h ), stream, scene_args( h ), walk_queue_args( h, cur ),
                       nullptr, d_pos_xy, first_pixel, base, h->d_accum, h->d_counters );
     HIP_TRY( hipGetLastError() );
@@ -784,6 +786,7 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
         HIP_TRY( hipMemsetAsync( h->q.counts, 0, sizeof( uint32_t ) * QC_CHILDREN, stream ) );
         HIP_TRY( hipMemsetAsync( h->q.counts + QC_RAYS, 0, sizeof( uint32_t ), stream ) );
         if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
+        h->shade_hit_recs += n_children;
         acn_launch_shade_hits( h->count_work, n_children, stream, scene_args( h ), walk_queue_args( h, cur ),
                                ( const HitRec* )h->q.children, h->d_accum, h->d_counters );
         HIP_TRY( hipGetLastError() );
@@ -814,7 +817,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     }
     h->events_used = 0;
     h->launches[ 0 ] = h->launches[ 1 ] = h->launches[ 2 ] = h->launches[ 3 ] = 0;
-    h->hard_rays = 0; h->walk_passes = 0;
+    h->hard_rays = 0; h->walk_passes = 0; h->walk_rays = 0; h->shade_hit_recs = 0;
     h->chunks = h->retries = h->levels = 0;
     h->peak_tasks = h->peak_children = 0;
     HIP_TRY( hipMemsetAsync( h->d_counters, 0, sizeof( unsigned long long ) * CNT_N, stream ) );
@@ -931,7 +934,7 @@ extern "C" int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms )
 
 extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
 {
-    if( !h || !out || n < 0 || n > 16 || !h->timed ) return fail( ACN_ERR_ARG, "no timed launch" );
+    if( !h || !out || n < 0 || n > 18 || !h->timed ) return fail( ACN_ERR_ARG, "no timed launch" );
     HIP_TRY( hipSetDevice( h->device ) );
     HIP_TRY( hipEventSynchronize( h->ev1 ) );
     double ms[ 4 ] = { 0, 0, 0, 0 };
@@ -943,10 +946,11 @@ extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
     }
     float total = 0;
     HIP_TRY( hipEventElapsedTime( &total, h->ev0, h->ev1 ) );
-    double v[ 16 ] = { ms[ 0 ], ms[ 1 ], ms[ 2 ], total, ( double )h->launches[ 0 ], ( double )h->launches[ 1 ], ( double )h->launches[ 2 ],
+    double v[ 18 ] = { ms[ 0 ], ms[ 1 ], ms[ 2 ], total, ( double )h->launches[ 0 ], ( double )h->launches[ 1 ], ( double )h->launches[ 2 ],
                        ( double )h->chunks, ( double )h->retries, ( double )h->levels, ( double )h->peak_tasks, ( double )h->peak_children,
-                       ( double )h->q.child_cap, ms[ 3 ], ( double )h->launches[ 3 ], ( double )h->hard_rays };
-    for( int k = 0; k < n; k++ ) out[ k ] = v[ k ];
+                       ( double )h->q.child_cap, ms[ 3 ], ( double )h->launches[ 3 ], ( double )h->hard_rays,
+                       ( double )h->walk_rays, ( double )h->shade_hit_recs };
+    for( int k = 0; k < n && k < 18; k++ ) out[ k ] = v[ k ];
     return ACN_OK;
 }
 

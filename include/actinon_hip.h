@@ -208,7 +208,8 @@ int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms );
 /* Per-stage device time of the last render call (HIP events on the launch stream) and pipeline statistics:
  * out[0] walk kernels ms, [1] shade kernels ms, [2] finalize ms, [3] total ms, [4..6] launches per stage, [7] chunks,
  * [8] overflow retries, [9] path levels run, [10] peak shading tasks, [11] peak child hits, [12] queue capacity,
- * [13] hard-ray kernels ms, [14] their launches, [15] hard rays. n <= 16. */
+ * [13] hard-ray kernels ms, [14] their launches, [15] hard rays, [16] rays traced by the specular walk (camera rays
+ * included), [17] path-sample hits shaded (levels >= 1). n <= 18. */
 int acn_last_stage_ms( acn_scene_handle* h, double* out, int n );
 
 /* Work counters of the last render call (rays cast, node visits ...), see DESIGN.md. n <= 16. */
