@@ -108,9 +108,13 @@ typedef double ACN_LDS* LdsF64P;
 typedef uint32_t ACN_LDS* LdsU32P;
 /* dynamic LDS of the machine kernels: [ staged node array (optional) ][ CSG stacks of the block's 256 lanes ] */
 extern __shared__ __attribute__( ( aligned( 16 ) ) ) double acn_lds_raw[];
-#define ACN_LDS_DEPTH 8                 /* stack levels kept in LDS; deeper nesting continues in scratch */
+#ifndef ACN_LDS_DEPTH
+#define ACN_LDS_DEPTH 3                 /* stack levels kept in LDS; deeper nesting continues in scratch */
+#endif
 #define ACN_LDS_LANES 256               /* block size of the kernels that provide the stack area */
-#define ACN_LDS_STACK_BYTES ( ACN_LDS_DEPTH * ACN_LDS_LANES * 16 )   /* per level and lane: a 8 B, w 4 B, side 4 B */
+/* per level and lane: a 8 B, parked normal 24 B, w 4 B, side 4 B; doubles first (alignment):
+ * [ a : D x 256 ][ nx, ny, nz : 3 x D x 256 ][ w : D x 256 ][ side : D x 256 ] */
+#define ACN_LDS_STACK_BYTES ( ACN_LDS_DEPTH * ACN_LDS_LANES * 40 )
 #define ACN_NO_LDS_STACK 0xFFFFFFFFu
 
 /* device-resident scene, parameterised by where the node array is read from */
@@ -684,7 +688,7 @@ DEV_SIDE int obj_side_dev( SR sc, int root, V3 pos, CT* cnt )
     uint32_t st[ ACN_CSG_MAX_DEPTH ];
     V3 aux[ ACN_CSG_MAX_DEPTH ];
     const bool lds = sc.lds_stack != ACN_NO_LDS_STACK;
-    LdsU32P ls = ( LdsU32P )( ( char ACN_LDS* )acn_lds_raw + sc.lds_stack ) + ACN_LDS_DEPTH * ACN_LDS_LANES * 3 + threadIdx.x;
+    LdsU32P ls = ( LdsU32P )( ( char ACN_LDS* )acn_lds_raw + sc.lds_stack ) + ACN_LDS_DEPTH * ACN_LDS_LANES * 9 + threadIdx.x;
     uint32_t cur = 0;
     int depth = 0, na = 0;
     int node = root;
@@ -787,7 +791,8 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
     V3       aux[ 2 * ACN_CSG_MAX_DEPTH ];  /* parked origins / directions */
     const bool lds = sc.lds_stack != ACN_NO_LDS_STACK;
     LdsF64P la = ( LdsF64P )( ( char ACN_LDS* )acn_lds_raw + sc.lds_stack ) + threadIdx.x;
-    LdsU32P lw = ( LdsU32P )( ( char ACN_LDS* )acn_lds_raw + sc.lds_stack ) + ACN_LDS_DEPTH * ACN_LDS_LANES * 2 + threadIdx.x;
+    LdsF64P ln = la + ACN_LDS_DEPTH * ACN_LDS_LANES;   /* x, y, z planes of the parked normals */
+    LdsU32P lw = ( LdsU32P )( ( char ACN_LDS* )acn_lds_raw + sc.lds_stack ) + ACN_LDS_DEPTH * ACN_LDS_LANES * 8 + threadIdx.x;
     uint32_t cur_w = 0;
     double cur_a = 0;                       /* pair: a1 (pc 2), walk offset (pc 3) | scale: d_factor */
     V3 cur_n1 = mk( 0, 0, 0 );
@@ -833,9 +838,17 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
         {
             if( depth > 0 )
             {
-                if( lds && depth <= ACN_LDS_DEPTH ) { lw[ ( depth - 1 ) * ACN_LDS_LANES ] = cur_w; la[ ( depth - 1 ) * ACN_LDS_LANES ] = cur_a; }
-                else                                { st_w[ depth - 1 ] = cur_w; st_a[ depth - 1 ] = cur_a; }
-                if( want_nor ) st_n[ depth - 1 ] = cur_n1;
+                if( lds && depth <= ACN_LDS_DEPTH )
+                {
+                    const int o = ( depth - 1 ) * ACN_LDS_LANES;
+                    lw[ o ] = cur_w; la[ o ] = cur_a;
+                    if( want_nor ) { ln[ o ] = cur_n1.x; ln[ o + ACN_LDS_DEPTH * ACN_LDS_LANES ] = cur_n1.y; ln[ o + 2 * ACN_LDS_DEPTH * ACN_LDS_LANES ] = cur_n1.z; }
+                }
+                else
+                {
+                    st_w[ depth - 1 ] = cur_w; st_a[ depth - 1 ] = cur_a;
+                    if( want_nor ) st_n[ depth - 1 ] = cur_n1;
+                }
             }
             depth++;
             if( rp_derived ) aux[ na++ ] = cur_rp;      /* na <= 2 * depth */
@@ -973,9 +986,17 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
                 depth--;
                 if( depth > 0 )
                 {
-                    if( lds && depth <= ACN_LDS_DEPTH ) { cur_w = lw[ ( depth - 1 ) * ACN_LDS_LANES ]; cur_a = la[ ( depth - 1 ) * ACN_LDS_LANES ]; }
-                    else                                { cur_w = st_w[ depth - 1 ]; cur_a = st_a[ depth - 1 ]; }
-                    if( want_nor ) cur_n1 = st_n[ depth - 1 ];
+                    if( lds && depth <= ACN_LDS_DEPTH )
+                    {
+                        const int o = ( depth - 1 ) * ACN_LDS_LANES;
+                        cur_w = lw[ o ]; cur_a = la[ o ];
+                        if( want_nor ) cur_n1 = mk( ln[ o ], ln[ o + ACN_LDS_DEPTH * ACN_LDS_LANES ], ln[ o + 2 * ACN_LDS_DEPTH * ACN_LDS_LANES ] );
+                    }
+                    else
+                    {
+                        cur_w = st_w[ depth - 1 ]; cur_a = st_a[ depth - 1 ];
+                        if( want_nor ) cur_n1 = st_n[ depth - 1 ];
+                    }
                 }
             }
         }
