@@ -151,10 +151,13 @@ struct Queues
     uint32_t  task_cap, child_cap, hard_cap, ray_cap;
 };
 
+#ifndef ACN_CLASS0_MIN
+#define ACN_CLASS0_MIN 32
+#endif
 /* lanes per task of the size classes, and the smallest sample count that goes to each */
 DEV int size_class( uint64_t n )
 {
-    return n > 32 ? 0 : n > 8 ? 1 : n > 2 ? 2 : 3;
+    return n > ACN_CLASS0_MIN ? 0 : n > 8 ? 1 : n > 2 ? 2 : 3;
 }
 
 /* one atomic per wave: every lane with `want` gets a distinct slot */
