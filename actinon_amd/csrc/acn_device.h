@@ -136,7 +136,8 @@ struct DevSceneT
     uint32_t prune_base; /* elems[ prune_base + node ]: offset of the node's prune program in elems[], or -1 */
     static constexpr bool prune = false;
 };
-/* the same scene for the kernel variants that run the interval-prune programs (only launched when the scene has any) */
+/* the same scene for the "extras" kernel variants: interval-prune programs and in-line simple compounds.  Launched
+ * only when the upload step produced either, so that the kernels of plain scenes (wine_glass) do not carry their code */
 template< class NP > struct DevScenePT : DevSceneT< NP > { static constexpr bool prune = true; };
 typedef DevSceneT< NodeP > DevScene;
 
@@ -1053,6 +1054,46 @@ DEVN double compound_ray_hit_dev( SR sc, int cmp, V3 rp, V3 rd, bool want_nor, V
     return min_a;
 }
 
+/* Simple compounds: a root element that is a compound whose whole subtree consists of nested compounds and simple
+ * leaves (many_spheres: 32 768 spheres under five levels of enveloped compounds).  The upload step lays its subtree
+ * out in pre-order with a skip link per entry ( node, index of the entry behind the subtree ), elems[ offset ] holding
+ * the entry count; compound_s_ray_hit (compound.c:215-243) then is a stackless loop: an enveloped compound that the
+ * ray misses is skipped by its link, everything else advances by one.  Same element order as the recursion, so ties
+ * between equal distances resolve identically.  No stack, no machine: k_shade runs it in line. */
+#define ACN_GFLAG_SIMPLE_COMPOUND 0x200u   /* device-only bit of GNode.flags */
+
+template< bool NOR, class SC, class CT >
+DEV double simple_compound_hit( const SC& sc, int cmp, V3 rp, V3 rd, V3* p_nor, int* hit_obj, double limit, CT* cnt )
+{
+    int base = sc.elems[ sc.prune_base + ( uint32_t )cmp ];
+    int count = sc.elems[ base ];
+    int i = base + 1, end = base + 1 + 2 * count;
+    double min_a = F3_INF;
+    while( i < end )
+    {
+        int node = sc.elems[ i ];
+        auto e = &sc.nodes[ node ];
+        if( e->type == ACN_COMPOUND )
+        {
+            i = ( node_has_env( e ) && !env_ray_hits( e, rp, rd ) ) ? sc.elems[ i + 1 ] : i + 2;
+            continue;
+        }
+        i += 2;
+        cnt->inc( CNT_OBJ_HIT );
+        if( node_has_env( e ) && !env_ray_hits( e, rp, rd ) ) continue;
+        V3 nor = mk( 0, 0, 0 );
+        double a = simple_leaf_hit( e, rp, rd, NOR, &nor );
+        if( a < min_a )
+        {
+            min_a = a;
+            if( NOR ) *p_nor = nor;
+            *hit_obj = node;
+            if( a <= limit ) return a;
+        }
+    }
+    return min_a;
+}
+
 /* Conservative pruning before a ray is handed to the CSG machine: surely_outside( n ) == true guarantees that the
  * whole ray lies outside n's bounding envelopes, in which case the reference returns f3_inf for n AND obj_side( n )
  * is +1 at every point of the ray:
@@ -1253,7 +1294,18 @@ DEV double element_hit( const SC& sc, int e, V3 rp, V3 rd, V3* nor, int* hit_obj
 {
     auto n = &sc.nodes[ e ];
     int type = n->type;
-    if( type == ACN_COMPOUND ) return compound_ray_hit_dev( sref( sc ), e, rp, rd, NOR, nor, hit_obj, limit, cnt );
+    if( type == ACN_COMPOUND )
+    {
+        if constexpr( SC::prune )   /* the "extras" kernel variants (DevScenePT) */
+        {
+            if( n->flags & ACN_GFLAG_SIMPLE_COMPOUND )
+            {
+                if( node_has_env( n ) && !env_ray_hits( n, rp, rd ) ) return F3_INF;
+                return simple_compound_hit< NOR >( sc, e, rp, rd, nor, hit_obj, limit, cnt );
+            }
+        }
+        return compound_ray_hit_dev( sref( sc ), e, rp, rd, NOR, nor, hit_obj, limit, cnt );
+    }
     *hit_obj = e;
     bool env = node_has_env( n );
     if( env && !env_ray_hits( n, rp, rd ) ) { cnt->inc( CNT_OBJ_HIT ); return F3_INF; }
@@ -1399,6 +1451,13 @@ DEV int root_occluded_fast( const SC& sc, int cmp, V3 rp, V3 rd, double limit, C
             double a = leaf_pair_element_hit< false >( sc, n, rp, rd, nullptr, cnt );
             if( a <= limit ) return 1;
         }
+        else if( SC::prune && ( n->flags & ACN_GFLAG_SIMPLE_COMPOUND ) )
+        {
+            if( node_has_env( n ) && !env_ray_hits( n, rp, rd ) ) continue;
+            int ho;
+            double a = simple_compound_hit< false >( sc, element, rp, rd, nullptr, &ho, limit, cnt );
+            if( a <= limit ) return 1;
+        }
         else if( type == ACN_COMPOUND || type == ACN_DISTANCE ? ( !node_has_env( n ) || env_ray_hits( n, rp, rd ) )
                                                               : !( surely_outside< ACN_PRUNE_DEPTH >( sc, element, rp, rd ) || ACN_FAST_PRUNE( sc, element, rp, rd, limit ) ) )
         {
@@ -1423,15 +1482,25 @@ DEV double root_trans_hit_fast( const SC& sc, int cmp, V3 rp, V3 rd, Trans* tran
         int element = __builtin_amdgcn_readfirstlane( sc.elems[ first + i ] );
         auto n = &sc.nodes[ element ];
         int type = n->type;
-        if( !is_fast_type( type ) && !( n->flags & ACN_GFLAG_LEAF_PAIR ) )
+        if( !is_fast_type( type ) && !( n->flags & ( ACN_GFLAG_LEAF_PAIR | ( SC::prune ? ACN_GFLAG_SIMPLE_COMPOUND : 0u ) ) ) )
         {
             if( type == ACN_COMPOUND || type == ACN_DISTANCE ? ( !node_has_env( n ) || env_ray_hits( n, rp, rd ) )
                                                              : !( surely_outside< ACN_PRUNE_DEPTH >( sc, element, rp, rd ) || ACN_FAST_PRUNE( sc, element, rp, rd, F3_INF ) ) ) h = true;
             continue;
         }
         V3 nor = mk( 0, 0, 0 );
-        double a = is_fast_type( type ) ? leaf_element_hit< true >( n, type, rp, rd, &nor, cnt )
-                                        : leaf_pair_element_hit< true >( sc, n, rp, rd, &nor, cnt );
+        double a;
+        if( is_fast_type( type ) ) a = leaf_element_hit< true >( n, type, rp, rd, &nor, cnt );
+        else if( n->flags & ACN_GFLAG_LEAF_PAIR ) a = leaf_pair_element_hit< true >( sc, n, rp, rd, &nor, cnt );
+        else
+        {
+            /* the hit object of a compound is the leaf that was hit (compound.c:225-243) */
+            a = F3_INF;
+            if constexpr( SC::prune )
+            {
+                if( !node_has_env( n ) || env_ray_hits( n, rp, rd ) ) a = simple_compound_hit< true >( sc, element, rp, rd, &nor, &element, -F3_INF, cnt );
+            }
+        }
         if( a < F3_INF )
         {
             if( a < min_a - F3_EPS )

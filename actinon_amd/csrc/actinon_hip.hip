@@ -499,6 +499,54 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
                 for( uint32_t w : prog ) elems2.push_back( ( int32_t )w );
             }
         }
+        /* simple compounds (acn_device.h: simple_compound_hit): pre-order ( node, skip ) tables for root elements that
+         * are compounds over nothing but compounds and simple leaves; the same per-node offset table locates them */
+        if( !getenv( "ACN_NO_SIMPLE_COMPOUNDS" ) )
+        {
+            std::vector< int8_t > simple( scene->n_nodes, -1 );
+            std::function< bool( int32_t ) > is_simple = [ & ]( int32_t i ) -> bool
+            {
+                if( simple[ i ] >= 0 ) return simple[ i ] != 0;
+                const acn_node& a = scene->nodes[ i ];
+                bool ok = a.type == ACN_PLANE || a.type == ACN_SPHERE || a.type == ACN_SQUAROID;
+                if( a.type == ACN_COMPOUND )
+                {
+                    ok = true;
+                    for( int32_t k = 0; k < a.child1 && ok; k++ ) ok = is_simple( scene->elems[ a.child0 + k ] );
+                }
+                simple[ i ] = ok ? 1 : 0;
+                return ok;
+            };
+            std::function< void( int32_t ) > emit = [ & ]( int32_t c )   /* children of compound c, depth first */
+            {
+                const acn_node& a = scene->nodes[ c ];
+                for( int32_t k = 0; k < a.child1; k++ )
+                {
+                    int32_t e = scene->elems[ a.child0 + k ];
+                    size_t at = elems2.size();
+                    elems2.push_back( e );
+                    elems2.push_back( 0 );
+                    if( scene->nodes[ e ].type == ACN_COMPOUND ) emit( e );
+                    elems2[ at + 1 ] = ( int32_t )elems2.size();   /* the entry behind e's subtree */
+                }
+            };
+            for( int root : { scene->light_root, scene->matter_root } )
+            {
+                const acn_node& r = scene->nodes[ root ];
+                for( int32_t k = 0; k < r.child1; k++ )
+                {
+                    int32_t e = scene->elems[ r.child0 + k ];
+                    if( scene->nodes[ e ].type != ACN_COMPOUND || !is_simple( e ) || elems2[ h->dev.prune_base + e ] >= 0 ) continue;
+                    size_t at = elems2.size();
+                    elems2[ h->dev.prune_base + e ] = ( int32_t )at;
+                    elems2.push_back( 0 );
+                    emit( e );
+                    elems2[ at ] = ( int32_t )( ( elems2.size() - at - 1 ) / 2 );
+                    nodes[ e ].flags |= ACN_GFLAG_SIMPLE_COMPOUND;
+                    h->prune = true;   /* the extras kernel variants */
+                }
+            }
+        }
         elems2.push_back( 0 );
     }
     HIP_TRY_H( hipMalloc( &h->d_elems, sizeof( int32_t ) * elems2.size() ) );
