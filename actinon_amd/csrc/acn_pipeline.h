@@ -366,10 +366,10 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
     q.children = nullptr; q.counts = p_counts; q.task_cap = task_cap; q.child_cap = 0; \
     q.hard_shadow = nullptr; q.hard_path = nullptr; q.hard_cap = 0; q.rays_out = p_rays_out; q.ray_cap = ray_cap;
 
-/* One pass of the specular walk: one lane per ray.  PRIMARY: the rays are the camera rays of the sample positions
+/* One pass of the specular walk: one lane per ray.  rays_in == nullptr: the rays are the camera rays of the sample positions
  * (lum_machine_s_func, scene.c:976-1011); otherwise they come from the ray queue the previous pass filled.  Each ray
  * is traced (scene_s_trans_hit) and its hit shaded; what it spawns goes to the next pass / the shading-task queues. */
-template< bool PRIMARY, bool COUNT, class SCL >
+template< bool COUNT, class SCL >
 DEV void trace_rays_body( const DevScene& sc, const SCL& scl, const Queues& q, const RayTask* __restrict__ rays_in,
                           const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n,
                           unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
@@ -382,7 +382,7 @@ DEV void trace_rays_body( const DevScene& sc, const SCL& scl, const Queues& q, c
     t.p = mk( 0, 0, 0 ); t.d = mk( 0, 0, 1 ); t.T = mk( 0, 0, 0 ); t.intensity = 0; t.depth = 0; t.pixel = 0;
     if( live )
     {
-        if( PRIMARY )
+        if( !rays_in )   /* the camera rays of the sample positions (wave-uniform branch) */
         {
             uint32_t pixel = base + i;
             double mx, my;
@@ -424,7 +424,7 @@ DEV void trace_rays_body( const DevScene& sc, const SCL& scl, const Queues& q, c
 #ifndef ACN_HPATH_WAVES
 #define ACN_HPATH_WAVES ACN_WALK_WAVES
 #endif
-template< bool PRIMARY, bool COUNT, bool LDS, bool PRUNE >
+template< bool COUNT, bool LDS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_TRACE_WAVES )
 void k_trace_rays( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __restrict__ rays_in,
                    const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n,
@@ -436,11 +436,11 @@ void k_trace_rays( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __res
     if constexpr( LDS )
     {
         ACN_STAGE_NODES( sc )
-        trace_rays_body< PRIMARY, COUNT >( sc, scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), q, rays_in, pos_xy, first_pixel, base, n, accum, counters );
+        trace_rays_body< COUNT >( sc, scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), q, rays_in, pos_xy, first_pixel, base, n, accum, counters );
     }
     else
     {
-        trace_rays_body< PRIMARY, COUNT >( sc, scene_view< PRUNE >( sc, sc.nodes ), q, rays_in, pos_xy, first_pixel, base, n, accum, counters );
+        trace_rays_body< COUNT >( sc, scene_view< PRUNE >( sc, sc.nodes ), q, rays_in, pos_xy, first_pixel, base, n, accum, counters );
     }
 }
 
@@ -551,7 +551,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 if( weight <= 0 ) continue;
                 double a;
                 if( LEAF_LIGHTS ) a = leaf_element_hit< false >( light_src, light_src->type, pos, out_d, nullptr, &cnt );
-                else { int ho; a = element_hit< false >( sc, light_idx, pos, out_d, nullptr, &ho, -F3_INF, &cnt ); }
+                else a = light_hit_call( sc, light_idx, pos, out_d, &cnt );
                 if( a >= F3_INF ) continue;
                 if( on_b > 0 ) weight = oren_nayar_weight( weight, theta_i, on_a, on_b, out_d, surface_d, ray_projection );
                 cnt.inc( CNT_SHADOW_RAY );

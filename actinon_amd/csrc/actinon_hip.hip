@@ -342,7 +342,13 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
                 if( x->type == ACN_NEG ) x = &scene->nodes[ x->child0 ];
                 return x->type == ACN_PLANE || x->type == ACN_SPHERE || x->type == ACN_SQUAROID;
             };
+            auto level1 = [ & ]( int32_t c )
+            {
+                const acn_node& x = scene->nodes[ c ];
+                return ( x.type == ACN_PAIR_INSIDE || x.type == ACN_PAIR_OUTSIDE ) && simple( x.child0 ) && simple( x.child1 );
+            };
             if( simple( a.child0 ) && simple( a.child1 ) ) g.flags |= ACN_GFLAG_LEAF_PAIR;
+            else if( ( simple( a.child0 ) || level1( a.child0 ) ) && ( simple( a.child1 ) || level1( a.child1 ) ) && !getenv( "ACN_NO_PAIR2" ) ) g.flags |= ACN_GFLAG_PAIR2;
         }
         memcpy( g.prm, a.prm, sizeof( g.prm ) );
         memcpy( g.pos, a.pos, sizeof( g.pos ) );
