@@ -1624,6 +1624,22 @@ DEV double oren_nayar_weight( double weight, double theta_i, double on_a, double
     return weight * ( on_a + ( on_b * f_max( cos_phi, 0 ) * s1 * ( s2 / c2 ) ) );
 }
 
+/* the same with sin / cos of theta_i supplied by the caller (one value per shading point, many samples): of the two
+ * angles only theta_r changes per sample, so one of the two sincos evaluations is loop invariant.  Bit-identical: the
+ * values used are the same function results as above. */
+DEV double oren_nayar_weight_pre( double weight, double theta_i, double sin_i, double cos_i, double on_a, double on_b, V3 out_d, V3 nor, V3 ray_prj )
+{
+    double theta_r = acn_acos( weight );
+    double cos_phi = -v_mlv( v_of_length( v_orthogonal_projection( out_d, nor ), 1.0 ), ray_prj );
+    double sr, cr;
+    acn_sincos( theta_r, &sr, &cr );
+    bool i_is_max = !( theta_i < theta_r );          /* f_max( theta_i, theta_r ) == theta_i (a > b ? a : b picks b on a tie) */
+    double s1 = i_is_max ? sin_i : sr;
+    double s2 = i_is_max ? sr : sin_i;
+    double c2 = i_is_max ? cr : cos_i;
+    return weight * ( on_a + ( on_b * f_max( cos_phi, 0 ) * s1 * ( s2 / c2 ) ) );
+}
+
 /* obj_color (objects.c:411-422): texture field if present (textures.c:99-102, 142-148), else prp.color.
  * obj_projection: plane objects.c:514-518, sphere :602-617, distance :893-896. */
 DEV V3 obj_color_dev( const DevScene& sc, int node, V3 pos )

@@ -518,6 +518,8 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
         const DTask ACN_CONST& t = ( ( const DTask ACN_CONST* )tasks )[ slot ];
         const V3 pos = ldc( t.pos ), surface_d = ldc( t.surface_d ), ray_projection = ldc( t.ray_projection );
         const double theta_i = t.theta_i, on_a = t.on_a, on_b = t.on_b, diffuse_intensity = t.diffuse_intensity;
+        double sin_i = 0, cos_i = 1;   /* loop invariant half of the Oren-Nayar term */
+        if( on_b > 0 ) acn_sincos( theta_i, &sin_i, &cos_i );
         uint64_t rv = t.rv;
         V3 lum = mk( 0, 0, 0 );   /* lum_l of scene.c:539, identical in all lanes of the group after each reduction */
 
@@ -553,7 +555,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 if( LEAF_LIGHTS ) a = leaf_element_hit< false >( light_src, light_src->type, pos, out_d, nullptr, &cnt );
                 else a = light_hit_call( sc, light_idx, pos, out_d, &cnt );
                 if( a >= F3_INF ) continue;
-                if( on_b > 0 ) weight = oren_nayar_weight( weight, theta_i, on_a, on_b, out_d, surface_d, ray_projection );
+                if( on_b > 0 ) weight = oren_nayar_weight_pre( weight, theta_i, sin_i, cos_i, on_a, on_b, out_d, surface_d, ray_projection );
                 cnt.inc( CNT_SHADOW_RAY );
                 V3 hit_pos = ray_pos( pos, out_d, a );
                 double diff_sqr = v_diff_sqr( hit_pos, light_pos );
@@ -610,7 +612,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 bool hard = false;
                 if( live )
                 {
-                    if( on_b > 0 ) weight = oren_nayar_weight( weight, theta_i, on_a, on_b, out_d, surface_d, ray_projection );
+                    if( on_b > 0 ) weight = oren_nayar_weight_pre( weight, theta_i, sin_i, cos_i, on_a, on_b, out_d, surface_d, ray_projection );
                     a = root_trans_hit_fast( scp, sc.matter_root, pos, out_d, &trans, &hard, &cnt );
                 }
                 bool hit = live && !hard && a < sc.prm.max_path_length;
