@@ -4,6 +4,7 @@ import ctypes as C
 ACN_ABI_VERSION = 2
 ACN_OPT_LINEAR_OUT = 1
 ACN_OPT_COUNT_WORK = 2
+ACN_OPT_STAGE_TIMING = 4
 
 ACN_OK, ACN_ERR_ARG, ACN_ERR_UNSUPPORTED, ACN_ERR_NO_FOV, ACN_ERR_DEVICE, ACN_ERR_CANCELLED = 0, -1, -2, -3, -4, -5
 

@@ -33,6 +33,8 @@ struct acn_scene_handle
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    int cur_stage = 0;
+    bool stage_timing = false;                 /* ACN_OPT_STAGE_TIMING of the current call */
     int max_csg_depth = 0;
     /* workspace of the wavefront pipeline */
     Queues q{};
@@ -676,8 +678,11 @@ static int ensure_workspace( acn_scene_handle* h, size_t n )
     return ACN_OK;
 }
 
+/* per-launch HIP events (stage times of acn_last_stage_ms) cost ~0.7 % of a frame and more of a small one: only
+ * with ACN_OPT_STAGE_TIMING; launch counts and pipeline statistics are kept either way */
 static int stage_begin( acn_scene_handle* h, int stage, hipStream_t stream )
 {
+    if( !h->stage_timing ) { h->cur_stage = stage; return ACN_OK; }
     if( h->events_used == h->events.size() )
     {
         StageEvents e{};
@@ -692,6 +697,7 @@ static int stage_begin( acn_scene_handle* h, int stage, hipStream_t stream )
 
 static int stage_end( acn_scene_handle* h, hipStream_t stream )
 {
+    if( !h->stage_timing ) { h->launches[ h->cur_stage ]++; return ACN_OK; }
     HIP_TRY( hipEventRecord( h->events[ h->events_used ].b, stream ) );
     h->launches[ h->events[ h->events_used ].stage ]++;
     h->events_used++;
@@ -860,6 +866,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     if( n > 0xFFFFFF00ull ) return fail( ACN_ERR_ARG, "too many positions in one call" );
     int linear = ( opts && ( opts->flags & ACN_OPT_LINEAR_OUT ) ) ? 1 : 0;
     h->count_work = ( opts && ( opts->flags & ACN_OPT_COUNT_WORK ) ) || getenv( "ACN_COUNT_WORK" ) != nullptr;
+    h->stage_timing = ( opts && ( opts->flags & ACN_OPT_STAGE_TIMING ) ) || getenv( "ACN_STAGE_TIMING" ) != nullptr;
     int st = ensure_workspace( h, n );
     if( st != ACN_OK ) return st;
     if( h->accum_cap < n )

@@ -217,6 +217,7 @@ class Handle:
         self.flat = flat
         self.device = device
         self.count_work = count_work   # instrumented kernels: last_counters() is only meaningful when set
+        self.stage_timing = False      # per-launch HIP events: last_stages() then carries walk / shade / hard ms
         self.h = C.c_void_p()
         check(hip.acn_scene_upload(C.byref(flat.c), device, C.byref(self.h)), "acn_scene_upload")
 
@@ -230,7 +231,8 @@ class Handle:
 
     def _opts(self, linear, stream):
         o = abi.RenderOpts()
-        o.flags = (abi.ACN_OPT_LINEAR_OUT if linear else 0) | (abi.ACN_OPT_COUNT_WORK if self.count_work else 0)
+        o.flags = ((abi.ACN_OPT_LINEAR_OUT if linear else 0) | (abi.ACN_OPT_COUNT_WORK if self.count_work else 0)
+                   | (abi.ACN_OPT_STAGE_TIMING if self.stage_timing else 0))
         o.stream = stream
         return o
 

@@ -150,6 +150,7 @@ typedef struct acn_flat_scene
 
 #define ACN_OPT_LINEAR_OUT 1u   /* skip cl_s_sat (src/vectors.h:372-384): caller accumulates / reduces first */
 #define ACN_OPT_COUNT_WORK 2u   /* run the instrumented kernels: acn_last_counters() reports rays / samples / hit tests */
+#define ACN_OPT_STAGE_TIMING 4u /* record HIP events around every launch: acn_last_stage_ms() reports per-stage times */
 
 typedef struct acn_render_opts
 {
@@ -205,7 +206,8 @@ int acn_resolve_dev( acn_scene_handle* h, const void* d_linear_rgb, size_t n, vo
 /* Timing of the kernels of the last render call on this handle (HIP events on the launch stream), ms. */
 int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms );
 
-/* Per-stage device time of the last render call (HIP events on the launch stream) and pipeline statistics:
+/* Per-stage device time of the last render call (HIP events on the launch stream; the per-stage values [0..2], [13]
+ * are zero unless the call had ACN_OPT_STAGE_TIMING, the total [3] is always measured) and pipeline statistics:
  * out[0] walk kernels ms, [1] shade kernels ms, [2] finalize ms, [3] total ms, [4..6] launches per stage, [7] chunks,
  * [8] overflow retries, [9] path levels run, [10] peak shading tasks, [11] peak child hits, [12] queue capacity,
  * [13] hard-ray kernels ms, [14] their launches, [15] hard rays, [16] rays traced by the specular walk (camera rays

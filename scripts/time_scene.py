@@ -10,6 +10,7 @@ sc = A.Scene.build(name, image_width=w, image_height=h, path_samples=ps, direct_
 flat = sc.flatten()
 print("build+flatten %.2f s nodes %d" % (time.time() - t0, flat.n_nodes), flush=True)
 H = A.Handle(flat)
+H.stage_timing = True
 out = torch.zeros((w * h, 3), dtype=torch.float64, device="cuda:0")
 for it in range(2):
     t0 = time.time()
