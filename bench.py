@@ -20,6 +20,8 @@ is fp64-ALU bound, so frac is tiny by nature -- see DESIGN.md); `cpu_baseline` i
 reference's algorithm; the reference itself needs the absent library beth) timed on the host cores on a strided
 pixel subset of the same frame.
 """
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before torch initialises HIP: the library's concurrent lanes need distinct hardware queues
 import argparse
 import json
 import os

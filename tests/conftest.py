@@ -1,4 +1,5 @@
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import subprocess
 import sys
 
