@@ -38,6 +38,11 @@ void acn_launch_shade1( KernelFlags, unsigned, hipStream_t, const SceneArgs&, co
 void acn_launch_trace( bool primary, KernelFlags f, uint32_t n, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
                        const WalkQueueArgs& q, const RayTask* rays_in, const double* pos_xy, size_t first_pixel, uint32_t base,
                        unsigned long long* accum, unsigned long long* counters );
+/* the tail of the walk in one launch (uninstrumented kernels only); chase_buf holds acn_chase_buffer_bytes( max rays ) */
+size_t acn_chase_buffer_bytes( uint32_t max_rays );
+void acn_launch_trace_chase( KernelFlags f, uint32_t n, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
+                             const WalkQueueArgs& q, const RayTask* rays_in, RayTask* chase_buf,
+                             unsigned long long* accum, unsigned long long* counters );
 void acn_launch_shade_hits( bool count, uint32_t n, hipStream_t stream, const SceneArgs& s, const WalkQueueArgs& q,
                             const HitRec* recs, unsigned long long* accum, unsigned long long* counters );
 void acn_launch_hard_shadow( KernelFlags f, uint32_t n, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,

@@ -137,7 +137,7 @@ struct HardPath
 };
 
 #define ACN_NCLASS 4
-enum { QC_TASKS = 0, QC_CLASS0 = 1, QC_CHILDREN = 5, QC_FLAGS = 6, QC_HARD_SHADOW = 7, QC_HARD_PATH = 8, QC_RAYS = 9, QC_N = 12 };
+enum { QC_TASKS = 0, QC_CLASS0 = 1, QC_CHILDREN = 5, QC_FLAGS = 6, QC_HARD_SHADOW = 7, QC_HARD_PATH = 8, QC_RAYS = 9, QC_CHASED = 10, QC_N = 12 };
 
 struct Queues
 {
@@ -147,6 +147,9 @@ struct Queues
     HardShadow* hard_shadow;
     HardPath*   hard_path;
     RayTask*    rays_out;           /* specular rays spawned by this pass, traced by the next one */
+    RayTask*    loc_out;            /* k_trace_chase: the block's own next-generation queue (else nullptr) ... */
+    uint32_t*   loc_count;          /* ... its counter (LDS) and capacity; what does not fit goes to rays_out */
+    uint32_t    loc_cap;
     uint32_t* counts;               /* QC_* */
     uint32_t  task_cap, child_cap, hard_cap, ray_cap;
 };
@@ -179,6 +182,16 @@ DEV uint32_t wave_alloc( uint32_t* counter, bool want )
  * block becomes a DTask. */
 DEV void push_ray( const Queues& q, bool want, V3 p, V3 d, V3 T, double intensity, int depth, uint32_t pixel )
 {
+    if( q.loc_out )   /* block-local queue of k_trace_chase (wave-uniform branch) */
+    {
+        uint32_t ls = wave_alloc( q.loc_count, want );
+        if( want && ls < q.loc_cap )
+        {
+            RayTask& c = q.loc_out[ ls ];
+            c.p = p; c.d = d; c.T = T; c.intensity = intensity; c.depth = depth; c.pixel = pixel;
+        }
+        want = want && ls >= q.loc_cap;   /* overflow of the local queue: the ray joins the next ordinary pass */
+    }
     uint32_t slot = wave_alloc( &q.counts[ QC_RAYS ], want );
     if( want )
     {
@@ -364,7 +377,29 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
     Queues q; \
     q.tasks = p_tasks; q.idx[ 0 ] = p_idx0; q.idx[ 1 ] = p_idx1; q.idx[ 2 ] = p_idx2; q.idx[ 3 ] = p_idx3; \
     q.children = nullptr; q.counts = p_counts; q.task_cap = task_cap; q.child_cap = 0; \
-    q.hard_shadow = nullptr; q.hard_path = nullptr; q.hard_cap = 0; q.rays_out = p_rays_out; q.ray_cap = ray_cap;
+    q.hard_shadow = nullptr; q.hard_path = nullptr; q.hard_cap = 0; q.rays_out = p_rays_out; q.ray_cap = ray_cap; \
+    q.loc_out = nullptr; q.loc_count = nullptr; q.loc_cap = 0;
+
+/* one ray: scene_s_trans_hit, then the hit is shaded; what it spawns goes to the queues.  Every lane of a wave must call
+ * this (the queue appends are wave-wide); lanes without a ray pass live = false. */
+template< class SCL, class CT >
+DEV void trace_one( const DevScene& sc, const SCL& scl, const Queues& q, const RayTask& t, bool live,
+                    unsigned long long* __restrict__ accum, CT* cnt )
+{
+    V3 acc = mk( 0, 0, 0 );
+    Trans trans;
+    trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
+    double offs = F3_INF;
+    if( live ) offs = scene_trans_hit_dev( scl, t.p, t.d, &trans, cnt );
+    bool hit = live && offs < F3_INF;
+    if( live && !hit )
+    {
+        V3 c = v_mlf( ld3( sc.prm.background_color ), t.intensity );
+        acc = v_mld( t.T, c );
+    }
+    shade_hit( sc, q, t.p, t.d, hit ? offs : 0.0, trans, hit ? t.depth : 0, t.intensity, t.T, t.pixel, acc, cnt );
+    if( live ) pixel_add( accum, t.pixel, acc );
+}
 
 /* One pass of the specular walk: one lane per ray.  rays_in == nullptr: the rays are the camera rays of the sample positions
  * (lum_machine_s_func, scene.c:976-1011); otherwise they come from the ray queue the previous pass filled.  Each ray
@@ -401,20 +436,7 @@ DEV void trace_rays_body( const DevScene& sc, const SCL& scl, const Queues& q, c
             t = rays_in[ i ];
         }
     }
-    V3 acc = mk( 0, 0, 0 );
-    Trans trans;
-    trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
-    double offs = F3_INF;
-    if( live ) offs = scene_trans_hit_dev( scl, t.p, t.d, &trans, &cnt );
-    bool hit = live && offs < F3_INF;
-    if( live && !hit )
-    {
-        V3 c = v_mlf( ld3( sc.prm.background_color ), t.intensity );
-        acc = v_mld( t.T, c );
-    }
-    /* all lanes call shade_hit (its queue appends are wave-wide); lanes without a hit pass depth 0 */
-    shade_hit( sc, q, t.p, t.d, hit ? offs : 0.0, trans, hit ? t.depth : 0, t.intensity, t.T, t.pixel, acc, &cnt );
-    if( live ) pixel_add( accum, t.pixel, acc );
+    trace_one( sc, scl, q, t, live, accum, &cnt );
     wave_add_counters( counters, cnt );
 }
 
@@ -442,6 +464,71 @@ void k_trace_rays( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __res
     {
         trace_rays_body< COUNT >( sc, scene_view< PRUNE >( sc, sc.nodes ), q, rays_in, pos_xy, first_pixel, base, n, accum, counters );
     }
+}
+
+/* The tail of the specular walk in ONE launch.  Late generations hold few rays, but every generation is a launch plus a
+ * host round trip, and a level has ~40 of them: on the share of a frame that one of 8 GPUs renders the chain of
+ * launches, not the work, sets the time.  Once a generation is small (ACN_CHASE_MAX rays) each block takes 256 of its
+ * rays and follows THEIR descendants by itself: children go to a block-private queue (two ping-pong regions of
+ * ACN_CHASE_CAP rays in global memory, counter in LDS) and are traced by the same block in the next round.  No block
+ * waits for another one, every loop is bounded (ACN_CHASE_ROUNDS), and whatever does not fit the private queue or is
+ * left after the last round goes to the ordinary ray queue for an ordinary pass -- so the kernel cannot hang and never
+ * loses a ray.  Per ray the computation is the one of k_trace_rays; only the order of queue entries differs, which the
+ * results do not depend on. */
+#define ACN_CHASE_CAP    2048
+#define ACN_CHASE_ROUNDS 64
+template< bool COUNT, bool LDS, bool PRUNE >
+__global__ __launch_bounds__( 256, ACN_TRACE_WAVES )
+void k_trace_chase( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __restrict__ rays_in, uint32_t n,
+                    RayTask* __restrict__ chase_buf, unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
+{
+    ACN_SCENE_VIEW
+    ACN_WALK_QUEUE_VIEW
+    if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;
+    if constexpr( LDS ) ACN_STAGE_NODES( sc )
+    __shared__ uint32_t loc_n[ 2 ];
+    Cnt< COUNT > cnt;
+    cnt.clear();
+    RayTask* region[ 2 ] = { chase_buf + ( size_t )blockIdx.x * 2 * ACN_CHASE_CAP, chase_buf + ( ( size_t )blockIdx.x * 2 + 1 ) * ACN_CHASE_CAP };
+    q.loc_cap = ACN_CHASE_CAP;
+    uint32_t traced = 0;
+    /* round 0 reads the block's 256 rays of the input generation, round r > 0 the private queue round r - 1 filled */
+    const RayTask* in = rays_in + ( size_t )blockIdx.x * blockDim.x;
+    uint32_t first = blockIdx.x * blockDim.x;
+    uint32_t n_loc = first < n ? ( n - first < blockDim.x ? n - first : blockDim.x ) : 0;
+    for( int round = 0; round <= ACN_CHASE_ROUNDS && n_loc > 0; round++ )
+    {
+        const int o = round & 1;
+        const bool last = round == ACN_CHASE_ROUNDS;    /* the last round only hands what is left to the ordinary queue */
+        if( threadIdx.x == 0 ) loc_n[ o ] = 0;
+        __syncthreads();
+        q.loc_out = last ? nullptr : region[ o ];
+        q.loc_count = &loc_n[ o ];
+        for( uint32_t j0 = 0; j0 < n_loc; j0 += blockDim.x )
+        {
+            uint32_t j = j0 + threadIdx.x;
+            bool live = j < n_loc;
+            RayTask t;
+            t.p = mk( 0, 0, 0 ); t.d = mk( 0, 0, 1 ); t.T = mk( 0, 0, 0 ); t.intensity = 0; t.depth = 0; t.pixel = 0;
+            if( live ) t = in[ j ];
+            if( last ) push_ray( q, live, t.p, t.d, t.T, t.intensity, t.depth, t.pixel );
+            else
+            {
+                if( live ) traced++;
+                if constexpr( LDS ) trace_one( sc, scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), q, t, live, accum, &cnt );
+                else                trace_one( sc, scene_view< PRUNE >( sc, sc.nodes ), q, t, live, accum, &cnt );
+            }
+        }
+        __syncthreads();
+        n_loc = last ? 0 : loc_n[ o ];
+        if( n_loc > ACN_CHASE_CAP ) n_loc = ACN_CHASE_CAP;   /* the excess went to the ordinary queue */
+        in = region[ o ];
+        __syncthreads();   /* loc_n[ o ] is read by everyone before the round after next resets it */
+    }
+    /* statistics: rays traced here */
+    for( int o = 32; o > 0; o >>= 1 ) traced += __shfl_down( traced, o );
+    if( ( threadIdx.x & 63 ) == 0 && traced ) atomicAdd( &p_counts[ QC_CHASED ], traced );
+    wave_add_counters( counters, cnt );
 }
 
 /* first pass of a level >= 1: one lane per path-sample hit (the recursive scene_s_lum call of scene.c:610) */
@@ -499,6 +586,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
     Queues q;
     q.tasks = nullptr; q.children = p_children; q.counts = p_counts; q.task_cap = 0; q.child_cap = child_cap;
     q.hard_shadow = p_hard_shadow; q.hard_path = p_hard_path; q.hard_cap = hard_cap; q.rays_out = nullptr; q.ray_cap = 0;
+    q.loc_out = nullptr; q.loc_count = nullptr; q.loc_cap = 0;
     constexpr int G = 64 / LPT;
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPT;

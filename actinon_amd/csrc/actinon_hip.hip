@@ -90,6 +90,7 @@ struct acn_scene_handle
     /* workspace of the wavefront pipeline */
     Queues q{};
     RayTask* rays[ 2 ] = { nullptr, nullptr };  /* ping-pong ray queues of the specular walk */
+    RayTask* chase_buf = nullptr;  uint32_t chase_max = 0;   /* block-private queues of k_trace_chase */
     uint32_t* h_counts = nullptr;              /* pinned */
     unsigned long long* d_accum = nullptr;  size_t accum_cap = 0;
     unsigned long long* d_counters = nullptr;
@@ -689,6 +690,8 @@ static void free_workspace( acn_scene_handle* h )
     if( h->q.hard_shadow ) hipFree( h->q.hard_shadow );
     if( h->q.hard_path ) hipFree( h->q.hard_path );
     for( int k = 0; k < 2; k++ ) { if( h->rays[ k ] ) hipFree( h->rays[ k ] ); h->rays[ k ] = nullptr; }
+    if( h->chase_buf ) hipFree( h->chase_buf );
+    h->chase_buf = nullptr; h->chase_max = 0;
     h->q.hard_shadow = nullptr; h->q.hard_path = nullptr; h->q.hard_cap = 0;
     h->q.tasks = nullptr; h->q.children = nullptr; h->q.task_cap = h->q.child_cap = 0;
     for( int k = 0; k < ACN_NCLASS; k++ ) h->q.idx[ k ] = nullptr;
@@ -837,16 +840,35 @@ static int walk_passes( acn_scene_handle* h, uint32_t n_in, int* cur, hipStream_
     {
         if( pass > 4096 ) return fail( ACN_ERR_DEVICE, "specular walk does not terminate" );
         int in = *cur, out = 1 - in;
-        HIP_TRY( hipMemsetAsync( h->q.counts + QC_RAYS, 0, sizeof( uint32_t ), stream ) );
+        HIP_TRY( hipMemsetAsync( h->q.counts + QC_RAYS, 0, 2 * sizeof( uint32_t ), stream ) );   /* QC_RAYS, QC_CHASED */
+        /* a small generation: one launch follows it and its descendants to the end (k_trace_chase) */
+        static const uint32_t chase_limit = getenv( "ACN_CHASE_MAX" ) ? ( uint32_t )atoll( getenv( "ACN_CHASE_MAX" ) ) : 32768u;
+        bool chase = !h->count_work && n_in <= chase_limit;
+        if( chase && h->chase_max < chase_limit )
+        {
+            if( h->chase_buf ) hipFree( h->chase_buf );
+            h->chase_buf = nullptr; h->chase_max = 0;
+            HIP_TRY( hipMalloc( &h->chase_buf, acn_chase_buffer_bytes( chase_limit ) ) );
+            h->chase_max = chase_limit;
+        }
         if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
+        if( chase )
+        {
+            acn_launch_trace_chase( kernel_flags( h ), n_in, machine_lds_bytes( h ), stream, scene_args( h ), walk_queue_args( h, out ),
+                                    ( const RayTask* )h->rays[ in ], h->chase_buf, h->d_accum, h->d_counters );
+        }
+        else
+        {
         h->walk_rays += n_in;
         acn_launch_trace( false, kernel_flags( h ), n_in, machine_lds_bytes( h ), stream, scene_args( h ), walk_queue_args( h, out ),
                           ( const RayTask* )h->rays[ in ], nullptr, 0, 0u, h->d_accum, h->d_counters );
+        }
         HIP_TRY( hipGetLastError() );
         if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
         if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
         if( ( st = check_flags( h, overflow ) ) != ACN_OK || *overflow ) return st;
         h->walk_passes++;
+        h->walk_rays += h->h_counts[ QC_CHASED ];
         n_in = h->h_counts[ QC_RAYS ];
         *cur = out;
     }
