@@ -842,7 +842,8 @@ static int walk_passes( acn_scene_handle* h, uint32_t n_in, int* cur, hipStream_
         int in = *cur, out = 1 - in;
         HIP_TRY( hipMemsetAsync( h->q.counts + QC_RAYS, 0, 2 * sizeof( uint32_t ), stream ) );   /* QC_RAYS, QC_CHASED */
         /* a small generation: one launch follows it and its descendants to the end (k_trace_chase) */
-        static const uint32_t chase_limit = getenv( "ACN_CHASE_MAX" ) ? ( uint32_t )atoll( getenv( "ACN_CHASE_MAX" ) ) : 32768u;
+        const char* chase_env = getenv( "ACN_CHASE_MAX" );
+        const uint32_t chase_limit = chase_env ? ( uint32_t )atoll( chase_env ) : 32768u;
         bool chase = !h->count_work && n_in <= chase_limit;
         if( chase && h->chase_max < chase_limit )
         {

@@ -196,3 +196,26 @@ def test_many_spheres_with_gpu_auto_envelopes(oracle):
     h.close()
     cpu = oracle.render_positions(flat, pos, linear=True)
     assert np.abs(gpu - cpu).max() <= TOL
+
+
+def test_lanes_and_generation_chase_do_not_change_a_pixel(oracle, monkeypatch):
+    """Concurrent lanes (ACN_LANES) and the fused tail of the specular walk (ACN_CHASE_MAX) reorganise the work, not the
+    arithmetic: the frame is bit-identical with and without them, and equals the oracle on a sample of its pixels."""
+    sc = A.Scene.build("wine_glass", image_width=320, image_height=180, path_samples=16, direct_samples=50)
+    flat = sc.flatten()
+    pos = S.positions(flat)
+    assert len(pos) >= 4 * 32 * 256          # enough tiles for four lanes
+    frames = {}
+    for label, lanes, chase in (("plain", "1", "0"), ("lanes", "4", "0"), ("chase", "1", "32768"), ("both", "4", "32768")):
+        monkeypatch.setenv("ACN_LANES", lanes)
+        monkeypatch.setenv("ACN_CHASE_MAX", chase)
+        h = A.Handle(flat)
+        frames[label] = (h.render_positions(pos, linear=True), h.last_stages())
+        h.close()
+    for label in ("lanes", "chase", "both"):
+        assert np.array_equal(frames[label][0], frames["plain"][0]), label
+        assert frames[label][1]["walk_rays"] == frames["plain"][1]["walk_rays"]
+    assert frames["chase"][1]["walk_launches"] < frames["plain"][1]["walk_launches"]
+    sample = np.arange(0, len(pos), 37)
+    cpu = oracle.render_positions(flat, pos[sample], linear=True)
+    assert np.abs(frames["both"][0][sample] - cpu).max() <= TOL
