@@ -218,6 +218,7 @@ class Handle:
         self.device = device
         self.count_work = count_work   # instrumented kernels: last_counters() is only meaningful when set
         self.stage_timing = False      # per-launch HIP events: last_stages() then carries walk / shade / hard ms
+        self.cancel = None             # optional ctypes.c_int polled by the library (acn_render_opts.cancel)
         self.h = C.c_void_p()
         check(hip.acn_scene_upload(C.byref(flat.c), device, C.byref(self.h)), "acn_scene_upload")
 
@@ -234,6 +235,8 @@ class Handle:
         o.flags = ((abi.ACN_OPT_LINEAR_OUT if linear else 0) | (abi.ACN_OPT_COUNT_WORK if self.count_work else 0)
                    | (abi.ACN_OPT_STAGE_TIMING if self.stage_timing else 0))
         o.stream = stream
+        if self.cancel is not None:
+            o.cancel = C.pointer(self.cancel)
         return o
 
     def render_positions(self, pos_xy, linear=False):

@@ -42,6 +42,9 @@ WORKLOADS = {
     # BASELINE.json configs[4]: the script's own settings (600x800, path 30 / direct 30); the scene comes from the
     # flattened fixture our interpreter produced from hanging_lamp.acn (tests/golden/make_scene_fixtures.py)
     "c5": ("fixture:hanging_lamp", dict()),
+    # BASELINE.json configs[4] at its stated size and sampling.  One frame is ~3e12 rays (the two nested path levels make
+    # the work quadratic in path_samples): a single GPU renders a strided pixel subset of the raster (--pixel-stride)
+    "c5full": ("fixture:hanging_lamp", dict(image_width=3840, image_height=2160, path_samples=1024, direct_samples=30)),
     "paraffin_lamp": ("fixture:paraffin_lamp", dict()),
 }
 
@@ -85,8 +88,10 @@ def cpu_baseline(flat, width, height, path_samples, target_seconds=15.0):
     cores = host_core_share()
     pos = A.main_pass_positions(width, height)
     n = pos.shape[0]
-    # calibrate on ~1/400 of the frame, then size the sample for ~target_seconds
-    probe = pos[:: max(1, n // 4096)]
+    # calibrate on a small strided probe (the oracle hands out 16 positions per lock, so no fewer than 64 per thread),
+    # then size the sample for ~target_seconds
+    probe_n = 4096 if path_samples < 256 else max(1024, 64 * cores)
+    probe = pos[:: max(1, n // probe_n)]
     t0 = time.perf_counter()
     o.render_positions(flat, probe, linear=True, threads=cores)
     dt = max(time.perf_counter() - t0, 1e-3)
@@ -115,6 +120,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="wine_glass_1080p", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true",
+                    help="heavy workloads: no extra passes for per-stage events and work counters after the timed steps")
+    ap.add_argument("--pixel-stride", type=int, default=1,
+                    help="render every K-th pixel of the raster only (heavy configs on one GPU); value counts the pixels rendered")
     ap.add_argument("--save-image", default=None, help="write the last frame as PNM (rank 0)")
     args = ap.parse_args()
 
@@ -157,6 +166,11 @@ def main():
 
     # resident inputs: this rank's pixel positions; accumulators
     idx_np = adist.rank_pixels(n_pix, rank, world)
+    if args.pixel_stride > 1:
+        if world != 1:
+            raise SystemExit("--pixel-stride is a single-GPU option")
+        idx_np = idx_np[::args.pixel_stride]
+        n_pix = idx_np.shape[0]
     pos = torch.from_numpy(adist.pixel_positions(idx_np, W)).to(dev)
     idx = torch.from_numpy(idx_np).to(dev)
     part = torch.empty((idx_np.shape[0], 3), dtype=torch.float64, device=dev)
@@ -209,17 +223,22 @@ def main():
         elapsed = float(t.item())
 
     # kernel duration of the dominant kernel: HIP events recorded by the library on the launch stream
-    handle.stage_timing = True          # per-launch events only here: they cost ~0.7 % of a frame
-    for _ in range(min(2, max(1, args.steps))):
-        step(True)
-    stages = handle.last_stages()
-    handle.stage_timing = False
-    # one extra, untimed pass through the instrumented kernels for the work counters
-    handle.count_work = True
-    step(False)
-    torch.cuda.synchronize()
-    counters = handle.last_counters()
-    handle.count_work = False
+    if args.quick:
+        kernel_ms.append(handle.last_kernel_ms())   # of the last timed step
+        stages = handle.last_stages()
+        counters = None
+    else:
+        handle.stage_timing = True          # per-launch events only here: they cost ~0.7 % of a frame
+        for _ in range(min(2, max(1, args.steps))):
+            step(True)
+        stages = handle.last_stages()
+        handle.stage_timing = False
+        # one extra, untimed pass through the instrumented kernels for the work counters
+        handle.count_work = True
+        step(False)
+        torch.cuda.synchronize()
+        counters = handle.last_counters()
+        handle.count_work = False
     k_ms = float(np.mean(kernel_ms))
 
     if rank == 0:
@@ -249,7 +268,8 @@ def main():
                                    f"trace_depth={int(flat.params.trace_depth)} (BASELINE.json configs[1] scene+sampling"
                                    f"{' at the metric resolution 1920x1080' if args.workload == 'wine_glass_1080p' else ''})"
                        if builder == "wine_glass" else f"{builder} {W}x{H} path_samples={S} direct_samples={int(flat.params.direct_samples)}",
-                       "pixels": n_pix, "path_samples": S, "partition": f"pixel tiles of {adist.TILE}, round-robin over {world} rank(s)",
+                       "pixels": n_pix, "path_samples": S,
+                       "pixel_subset": (f"every {args.pixel_stride}th pixel of the {W}x{H} raster" if args.pixel_stride > 1 else "all"), "partition": f"pixel tiles of {adist.TILE}, round-robin over {world} rank(s)",
                        "reduce": "RCCL all_reduce(sum, f64, W*H*3)" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, world),
@@ -258,9 +278,10 @@ def main():
                          "note": "the path is fp64-VALU-issue bound with divergent CSG traversal; the HBM roofline is "
                                  "reported because BASELINE.json asks for it (DESIGN.md 7)"},
             "stages": stages,
-            "work": {"rays_per_step_rank0": counters["trans_rays"] + counters["shadow_rays"],
-                     "obj_hit_tests_rank0": counters["obj_hits"],
-                     "grays_per_s_rank0": (counters["trans_rays"] + counters["shadow_rays"]) / (k_ms * 1e-3) / 1e9},
+            "work": None if counters is None else {
+                "rays_per_step_rank0": counters["trans_rays"] + counters["shadow_rays"],
+                "obj_hit_tests_rank0": counters["obj_hits"],
+                "grays_per_s_rank0": (counters["trans_rays"] + counters["shadow_rays"]) / (k_ms * 1e-3) / 1e9},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flat, W, H, S)

@@ -1,0 +1,147 @@
+"""BASELINE.json configs[2..4] at their STATED size and sampling on the GPU, against the CPU oracle.
+
+The oracle needs hours for a whole frame at these settings (the reference's radiance recursion nests two path levels,
+src/scene.c:584-621: every first-level path sample whose hit is diffuse starts another path_samples * intensity
+loop), so parity is checked on a strided subset of the full raster: the camera, the scene, path_samples, direct_samples,
+trace_depth and the pixel -> ray mapping are the config's own, only the number of pixels looked at is reduced.  That puts
+the code paths only these configs reach under the oracle: the 5-level / 37 449-node many_spheres scene that does not fit
+LDS, 8- and 16-iteration sample loops of the 64-lane shading kernel, thousands of path-sample hits per pixel, and the
+chunking of a call.
+
+Also here: the queue-overflow retry path (a chunk whose records do not fit is halved and redone) and the cancel flag of
+acn_render_opts inside the library.
+"""
+import ctypes as C
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import actinon_amd as A
+import scenes_util as S
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# name -> (builder, overrides, pixels looked at)
+CONFIGS = {
+    # many_spheres.acn:23-43,62-98: 8^5 spheres under five levels of enveloped compounds, auto envelopes from the
+    # Monte-Carlo estimator (run on the GPU, as `many_spheres:5:0` asks)
+    "c3_many_spheres": ("many_spheres:5:0", dict(image_width=1920, image_height=1080, path_samples=256, direct_samples=20), 2048),
+    # diamond.acn:23-43,194-212
+    "c4_diamond": ("diamond", dict(image_width=1920, image_height=1080, path_samples=512, direct_samples=50), 2048),
+    # hanging_lamp/hanging_lamp.acn:26-47 through the flattened fixture (2 847 nodes)
+    "c5_hanging_lamp": ("fixture:hanging_lamp", dict(image_width=3840, image_height=2160, path_samples=1024, direct_samples=30), 1024),
+}
+
+
+def load(builder, ov):
+    if builder.startswith("fixture:"):
+        return A.Flat.load(os.path.join(HERE, "golden", "scenes", builder.split(":")[1] + ".npz"), **ov)
+    sc = A.Scene.build(builder, **ov)
+    return sc.flatten()
+
+
+def strided_positions(flat, count):
+    """`count` pixel centres spread over the whole raster: every (W*H // count)-th pixel in raster order, the stride
+    made odd so that the columns drift from row to row."""
+    w, h = int(flat.params.image_width), int(flat.params.image_height)
+    stride = (w * h // count) | 1
+    idx = np.arange(0, w * h, stride)[:count]
+    return A.main_pass_positions(w, h)[idx]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    assert A.device_count() >= 1, "no HIP device: the gpu tests must run on the GPU box"
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_config_at_stated_size_matches_oracle_on_strided_pixels(oracle, name):
+    builder, ov, count = CONFIGS[name]
+    flat = load(builder, ov)
+    assert int(flat.params.path_samples) == ov["path_samples"] and int(flat.params.image_width) == ov["image_width"]
+    pos = strided_positions(flat, count)
+    assert len(pos) == count
+    h = A.Handle(flat)
+    gpu = h.render_positions(pos, linear=True)
+    st = h.last_stages()
+    h.close()
+    t0 = time.time()
+    cpu = oracle.render_positions(flat, pos, linear=True)
+    print(f"{name}: {count} pixels, gpu {st['total_ms']:.0f} ms ({st['chunks']:.0f} chunks, {st['levels']:.0f} levels, "
+          f"peak children {st['peak_children']:.0f}), oracle {time.time() - t0:.1f} s")
+    err = np.abs(gpu - cpu)
+    assert err.max() <= TOL, f"{name}: {(err > TOL).any(axis=1).sum()} of {count} pixels differ, max {err.max():.3e}"
+    assert np.array_equal(A.cps_from_cl(np.clip(gpu, 0, None) ** flat.params.gamma), A.cps_from_cl(np.clip(cpu, 0, None) ** flat.params.gamma))
+    # the subset is not degenerate: it sees objects, not only background
+    assert gpu.std() > 1e-3
+
+
+def test_queue_overflow_retry_is_bit_identical(oracle, monkeypatch):
+    """A chunk whose path-sample hits do not fit the queues is halved and redone (launch_render in actinon_hip.hip).
+    Forced here with a small workspace and a chunk that is too large for it; the image must not change by a bit."""
+    sc = A.Scene.build("wine_glass", image_width=320, image_height=180, path_samples=64, direct_samples=50)
+    flat = sc.flatten()
+    pos = S.positions(flat)
+    monkeypatch.setenv("ACN_LANES", "1")
+    h = A.Handle(flat)
+    ref = h.render_positions(pos, linear=True)
+    st_ref = h.last_stages()
+    h.close()
+    assert st_ref["retries"] == 0
+    monkeypatch.setenv("ACN_WORKSPACE_MB", "48")          # 65 536 records per queue (the floor)
+    monkeypatch.setenv("ACN_CHUNK", str(len(pos)))        # every position in one chunk: ~3 hits per pixel do not fit
+    h = A.Handle(flat)
+    forced = h.render_positions(pos, linear=True)
+    st = h.last_stages()
+    h.close()
+    assert st["retries"] > 0 and st["chunks"] > 1, st
+    assert np.array_equal(forced, ref)
+    # ... and through the concurrent lanes, each with its share of the small workspace
+    monkeypatch.setenv("ACN_LANES", "4")
+    monkeypatch.setenv("ACN_WORKSPACE_MB", "192")
+    h = A.Handle(flat)
+    forced4 = h.render_positions(pos, linear=True)
+    st4 = h.last_stages()
+    h.close()
+    assert st4["retries"] > 0, st4
+    assert np.array_equal(forced4, ref)
+    sample = np.arange(0, len(pos), 53)
+    cpu = oracle.render_positions(flat, pos[sample], linear=True)
+    assert np.abs(forced[sample] - cpu).max() <= TOL
+
+
+def test_cancel_flag_inside_the_library(monkeypatch):
+    """acn_render_opts.cancel is the SIGINT flag of src/scene.c:893,978: set before the call nothing is rendered; set
+    while the call is running the library stops between two chunks and returns ACN_ERR_CANCELLED."""
+    sc = A.Scene.build("diamond", image_width=256, image_height=256, path_samples=128, direct_samples=50)
+    flat = sc.flatten()
+    pos = S.positions(flat)
+    monkeypatch.setenv("ACN_CHUNK", "512")                # many chunks: many polls
+    for lanes in ("1", "4"):
+        monkeypatch.setenv("ACN_LANES", lanes)
+        h = A.Handle(flat)
+        h.cancel = C.c_int(1)
+        with pytest.raises(A.AcnError) as e:
+            h.render_positions(pos)
+        assert e.value.status == A.abi.ACN_ERR_CANCELLED
+        h.cancel = C.c_int(0)
+        flag = h.cancel
+        timer = threading.Timer(0.05, lambda: setattr(flag, "value", 1))
+        t0 = time.time()
+        timer.start()
+        with pytest.raises(A.AcnError) as e:
+            h.render_positions(pos)
+        dt = time.time() - t0
+        timer.cancel()
+        assert e.value.status == A.abi.ACN_ERR_CANCELLED
+        assert dt < 30, dt
+        # the handle stays usable
+        h.cancel = None
+        small = h.render_positions(pos[:512], linear=True)
+        assert np.isfinite(small).all()
+        h.close()
