@@ -17,7 +17,7 @@ oracle: oracle/libacn_oracle.so oracle/libacn_oracle_libm.so
 cli: actinon_amd/bin/actinon_hip
 
 # one object per kernel family: `make -j` compiles them side by side (acn_launch.h)
-HIP_UNITS := actinon_hip k_shade_64 k_shade_16 k_shade_4 k_shade_1 k_trace k_trace_count k_chase k_hard_shadow k_hard_path
+HIP_UNITS := actinon_hip k_shade_64 k_shade_16 k_shade_4 k_shade_1 k_walk_lds k_walk_glb k_walk_count k_hard_shadow k_hard_path
 HIP_OBJS  := $(addprefix build/,$(addsuffix .o,$(HIP_UNITS)))
 build/%.o: actinon_amd/csrc/%.hip $(wildcard actinon_amd/csrc/*.h) include/actinon_hip.h
 	@mkdir -p build

@@ -187,6 +187,7 @@ template< class NP > struct SceneRefT { NP nodes; ElemP elems; uint32_t* flags; 
 #define ACN_FLAG_TASK_OVERFLOW  1u
 #define ACN_FLAG_CHILD_OVERFLOW 2u
 #define ACN_FLAG_STACK_OVERFLOW 4u   /* CSG / compound / ray stack exhausted: the result would be wrong, the call fails */
+#define ACN_FLAG_CLAMPED        8u   /* a single pixel contribution exceeded the fixed-point clamp (reported, not an error) */
 template< class NP > __device__ __forceinline__ SceneRefT< NP > sref( const DevSceneT< NP >& sc ) { SceneRefT< NP > r; r.nodes = sc.nodes; r.elems = sc.elems; r.flags = sc.flags; r.n_elems = sc.n_elems; r.lds_stack = sc.lds_stack; return r; }
 
 /* ---- vectors.h ---- */

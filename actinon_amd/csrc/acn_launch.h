@@ -1,5 +1,5 @@
 /* acn_launch.h -- launch wrappers of the templated pipeline kernels, one translation unit per kernel family
- * (k_shade_*.hip, k_trace.hip, k_hard.hip) so that `make -j` compiles the families in parallel: the 50-odd kernel
+ * (k_shade_*.hip, k_walk_*.hip, k_hard_*.hip) so that `make -j` compiles the families in parallel: the 50-odd kernel
  * instantiations in one file took 8.5 minutes, the families side by side take about 3.  The wrappers pick the
  * instantiation from runtime flags; the orchestration stays in actinon_hip.hip. */
 #ifndef ACN_LAUNCH_H
@@ -20,53 +20,69 @@ struct SceneArgs
 /* variant selection: instrumented kernels (count) never carry prune programs */
 struct KernelFlags { bool count, leaf_lights, lds_nodes, prune; };
 
-/* ACN_WALK_QUEUE_PARAMS */
-struct WalkQueueArgs
+/* the queues of one pipeline run (a handle's or a lane's workspace) as the kernels of path level L see them:
+ * `counts` is the level's counter block, `prev_children` the QC_CHILDREN word of the level before */
+struct LevelQ
 {
-    DTask* tasks; uint32_t* idx[ 4 ]; uint32_t* counts; uint32_t task_cap; RayTask* rays_out; uint32_t ray_cap;
+    DTask* tasks; uint32_t* idx[ ACN_NCLASS ]; uint32_t task_cap;
+    HitRec* children; uint32_t child_cap;
+    HardShadow* hard_shadow; HardPath* hard_path; uint32_t hard_cap;
+    RayTask* rays_a; RayTask* rays_b; uint32_t ray_cap;     /* a: k_shade_hits -> k_walk; b: k_walk -> mop-up launch */
+    RayTask* stacks; uint32_t stack_cap;                    /* private ray stacks of the k_walk waves: grid * 4 of them */
+    uint32_t stack_use;                                     /* slots of a stack the first walk launch of a level uses (< stack_cap: tests) */
+    uint32_t* counts;
+    const uint32_t* prev_children;
+    unsigned grid;                                          /* workgroups of the persistent kernels */
+    unsigned shade_grid;                                    /* workgroups of k_shade */
 };
 
-void acn_launch_shade( int lanes_per_task, KernelFlags f, unsigned blocks, hipStream_t stream, const SceneArgs& s,
-                       const DTask* tasks, const uint32_t* idx, uint32_t n_tasks, HitRec* children, uint32_t child_cap,
-                       HardShadow* hard_shadow, HardPath* hard_path, uint32_t hard_cap, uint32_t* counts,
+/* one launch of the specular walk.  n_cam > 0: the fresh input are the camera rays of positions [ base, base + n_cam );
+ * n_cam == 0: the ray queue rays_a (mop == false) or the overflow queue rays_b of the launch before (mop == true) */
+void acn_launch_walk( KernelFlags f, bool mop, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
+                      const double* pos_xy, size_t first_pixel, uint32_t base, uint32_t n_cam,
+                      unsigned long long* accum, unsigned long long* counters );
+void acn_launch_shade_hits( bool count, const LevelQ& q, hipStream_t stream, const SceneArgs& s,
+                            unsigned long long* accum, unsigned long long* counters );
+void acn_launch_shade( int cls, KernelFlags f, const LevelQ& q, hipStream_t stream, const SceneArgs& s,
                        unsigned long long* accum, unsigned long long* counters );
-void acn_launch_shade64( KernelFlags, unsigned, hipStream_t, const SceneArgs&, const DTask*, const uint32_t*, uint32_t, HitRec*, uint32_t, HardShadow*, HardPath*, uint32_t, uint32_t*, unsigned long long*, unsigned long long* );
-void acn_launch_shade16( KernelFlags, unsigned, hipStream_t, const SceneArgs&, const DTask*, const uint32_t*, uint32_t, HitRec*, uint32_t, HardShadow*, HardPath*, uint32_t, uint32_t*, unsigned long long*, unsigned long long* );
-void acn_launch_shade4( KernelFlags, unsigned, hipStream_t, const SceneArgs&, const DTask*, const uint32_t*, uint32_t, HitRec*, uint32_t, HardShadow*, HardPath*, uint32_t, uint32_t*, unsigned long long*, unsigned long long* );
-void acn_launch_shade1( KernelFlags, unsigned, hipStream_t, const SceneArgs&, const DTask*, const uint32_t*, uint32_t, HitRec*, uint32_t, HardShadow*, HardPath*, uint32_t, uint32_t*, unsigned long long*, unsigned long long* );
-
-void acn_launch_trace( bool primary, KernelFlags f, uint32_t n, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
-                       const WalkQueueArgs& q, const RayTask* rays_in, const double* pos_xy, size_t first_pixel, uint32_t base,
-                       unsigned long long* accum, unsigned long long* counters );
-/* the tail of the walk in one launch (uninstrumented kernels only); chase_buf holds acn_chase_buffer_bytes( max rays ) */
-size_t acn_chase_buffer_bytes( uint32_t max_rays );
-void acn_launch_trace_chase( KernelFlags f, uint32_t n, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
-                             const WalkQueueArgs& q, const RayTask* rays_in, RayTask* chase_buf,
+void acn_launch_shade64( KernelFlags, const LevelQ&, hipStream_t, const SceneArgs&, unsigned long long*, unsigned long long* );
+void acn_launch_shade16( KernelFlags, const LevelQ&, hipStream_t, const SceneArgs&, unsigned long long*, unsigned long long* );
+void acn_launch_shade4( KernelFlags, const LevelQ&, hipStream_t, const SceneArgs&, unsigned long long*, unsigned long long* );
+void acn_launch_shade1( KernelFlags, const LevelQ&, hipStream_t, const SceneArgs&, unsigned long long*, unsigned long long* );
+void acn_launch_hard_shadow( KernelFlags f, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
                              unsigned long long* accum, unsigned long long* counters );
-void acn_launch_shade_hits( bool count, uint32_t n, hipStream_t stream, const SceneArgs& s, const WalkQueueArgs& q,
-                            const HitRec* recs, unsigned long long* accum, unsigned long long* counters );
-void acn_launch_hard_shadow( KernelFlags f, uint32_t n, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
-                             const HardShadow* recs, uint32_t* counts, unsigned long long* accum, unsigned long long* counters );
-void acn_launch_hard_path( KernelFlags f, uint32_t n, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
-                           const HardPath* recs, HitRec* children, uint32_t child_cap, uint32_t* counts,
+void acn_launch_hard_path( KernelFlags f, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
                            unsigned long long* accum, unsigned long long* counters );
 
 #define ACN_SCENE_ARGS_OF( s ) ( s ).dev, ( s ).nodes, ( s ).mats, ( s ).elems, ( s ).textures
+#define ACN_TASKQ_ARGS_OF( q ) ( q ).tasks, ( q ).idx[ 0 ], ( q ).idx[ 1 ], ( q ).idx[ 2 ], ( q ).idx[ 3 ], ( q ).counts, ( q ).task_cap
+
+/* k_walk< C, L, R > for the three kinds of fresh input */
+#define ACN_LW_( C, L, R ) do { \
+    if( n_cam ) \
+        hipLaunchKernelGGL( ( k_walk< C, L, R > ), dim3( q.grid ), dim3( 256 ), lds_bytes, stream, ACN_SCENE_ARGS_OF( s ), ACN_TASKQ_ARGS_OF( q ), \
+            ( const RayTask* )nullptr, ( const uint32_t* )nullptr, 0u, pos_xy, first_pixel, base, n_cam, \
+            ( uint32_t )QC_CUR_WALK, ( uint32_t )QC_RAYS_OVF, q.rays_b, q.ray_cap, q.stacks, q.stack_cap, q.stack_use, accum, counters ); \
+    else if( !mop ) \
+        hipLaunchKernelGGL( ( k_walk< C, L, R > ), dim3( q.grid ), dim3( 256 ), lds_bytes, stream, ACN_SCENE_ARGS_OF( s ), ACN_TASKQ_ARGS_OF( q ), \
+            ( const RayTask* )q.rays_a, ( const uint32_t* )( q.counts + QC_RAYS ), q.ray_cap, ( const double* )nullptr, ( size_t )0, 0u, 0u, \
+            ( uint32_t )QC_CUR_WALK, ( uint32_t )QC_RAYS_OVF, q.rays_b, q.ray_cap, q.stacks, q.stack_cap, q.stack_use, accum, counters ); \
+    else \
+        hipLaunchKernelGGL( ( k_walk< C, L, R > ), dim3( q.grid ), dim3( 256 ), lds_bytes, stream, ACN_SCENE_ARGS_OF( s ), ACN_TASKQ_ARGS_OF( q ), \
+            ( const RayTask* )q.rays_b, ( const uint32_t* )( q.counts + QC_RAYS_OVF ), q.ray_cap, ( const double* )nullptr, ( size_t )0, 0u, 0u, \
+            ( uint32_t )QC_CUR_MOP, ( uint32_t )QC_RAYS_OVF2, ( RayTask* )nullptr, 0u, q.stacks, q.stack_cap, q.stack_cap, accum, counters ); \
+    } while( 0 )
 
 /* body of acn_launch_shade<LPT>: shared by the four k_shade translation units */
-#define ACN_DEFINE_LAUNCH_SHADE( NAME, LPT ) \
-void NAME( KernelFlags f, unsigned blocks, hipStream_t stream, const SceneArgs& s, const DTask* tasks, const uint32_t* idx, \
-           uint32_t n_tasks, HitRec* children, uint32_t child_cap, HardShadow* hard_shadow, HardPath* hard_path, \
-           uint32_t hard_cap, uint32_t* counts, unsigned long long* accum, unsigned long long* counters ) \
+#define ACN_DEFINE_LAUNCH_SHADE( NAME, LPT, CLS ) \
+void NAME( KernelFlags f, const LevelQ& q, hipStream_t stream, const SceneArgs& s, unsigned long long* accum, unsigned long long* counters ) \
 { \
-    _Pragma( "clang diagnostic push" ) \
     /* the prune-program variants exist for the uninstrumented kernels only; count_work runs the plain ones */ \
-    if( f.count )      { if( f.leaf_lights ) ACN_LS_( LPT, true, true, false );  else ACN_LS_( LPT, true, false, false ); } \
-    else if( f.prune ) { if( f.leaf_lights ) ACN_LS_( LPT, false, true, true );  else ACN_LS_( LPT, false, false, true ); } \
-    else               { if( f.leaf_lights ) ACN_LS_( LPT, false, true, false ); else ACN_LS_( LPT, false, false, false ); } \
-    _Pragma( "clang diagnostic pop" ) \
+    if( f.count )      { if( f.leaf_lights ) ACN_LS_( LPT, CLS, true, true, false );  else ACN_LS_( LPT, CLS, true, false, false ); } \
+    else if( f.prune ) { if( f.leaf_lights ) ACN_LS_( LPT, CLS, false, true, true );  else ACN_LS_( LPT, CLS, false, false, true ); } \
+    else               { if( f.leaf_lights ) ACN_LS_( LPT, CLS, false, true, false ); else ACN_LS_( LPT, CLS, false, false, false ); } \
 }
-#define ACN_LS_( LPT, C, L, P ) hipLaunchKernelGGL( ( k_shade< LPT, C, L, P > ), dim3( blocks ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS_OF( s ), \
-    tasks, idx, n_tasks, children, child_cap, hard_shadow, hard_path, hard_cap, counts, accum, counters )
+#define ACN_LS_( LPT, CLS, C, L, P ) hipLaunchKernelGGL( ( k_shade< LPT, C, L, P > ), dim3( q.shade_grid ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS_OF( s ), \
+    ( const DTask* )q.tasks, ( const uint32_t* )q.idx[ CLS ], CLS, q.task_cap, q.children, q.child_cap, q.hard_shadow, q.hard_path, q.hard_cap, q.counts, accum, counters )
 
 #endif

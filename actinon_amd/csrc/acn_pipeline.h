@@ -1,28 +1,41 @@
-/* acn_pipeline.h -- the level-synchronous wavefront formulation of scene_s_lum (src/scene.c:420-667) for gfx950.
+/* acn_pipeline.h -- the wavefront formulation of scene_s_lum (src/scene.c:420-667) for gfx950.
  *
  * The reference evaluates one pixel by a branching recursion: specular chains (Fresnel reflection / chromatic
  * reflection / refraction, depth-1 each) with, at every diffuse shading point, a direct-light loop over
  * direct_samples*I cap samples per light and -- while depth > 10 -- a path loop over path_samples*I hemisphere
  * samples whose hits recurse with depth-10.  Every term is linear in what the recursion returns, so each pending
  * piece of work carries a colour throughput T and adds T * value into its pixel.  That turns the recursion into
- * three kinds of records and two kernels that alternate once per path level:
+ * records in HBM-resident queues and a fixed chain of kernels per path level, none of which needs the host:
  *
- *   k_walk   (one LANE per sample position or per child hit)    primary ray / child hit -> depth-first walk of the
- *            specular tree with a small per-lane ray stack; light hits and background go straight to the pixel;
- *            every diffuse shading point becomes a DTask, appended to a size-class queue through a wave
- *            ballot + prefix (one atomic per wave and class).
- *   k_shade  (one WAVEFRONT per DTask; 16 / 4 / 1 lanes per task for the small size classes)   lanes = samples:
- *            lane j jumps the shading point's LCG stream ahead by 2j draws (the reference consumes exactly two
- *            draws per sample, scene.c:558,598), casts its cap sample at the light, Oren-Nayar weight, shadow ray;
- *            then the path samples: hemisphere sample, transition hit against matter; misses take the background,
- *            hits are compacted (ballot + prefix) into the HitRec queue of the next level.
+ *   k_walk        persistent waves.  A wave owns a private LIFO stack of pending specular rays (global memory) and
+ *                 works in steps of 64 rays: whatever the stack holds, topped up with fresh input (camera rays of the
+ *                 chunk's sample positions, or the ray queue k_shade_hits filled) fetched through one atomic cursor.
+ *                 Each ray is traced (scene_s_trans_hit) and its hit shaded: light / background terms go to the
+ *                 pixel, Fresnel / chromatic / refraction children back onto the wave's own stack, the diffuse block
+ *                 becomes a DTask in a size-class queue.  No wave ever waits for another one: the whole specular
+ *                 walk of a level -- up to trace_depth generations -- is ONE launch with full waves throughout.
+ *   k_shade       one WAVEFRONT per DTask (16 / 4 / 1 lanes per task for the small size classes), lanes = samples:
+ *                 lane j jumps the shading point's LCG stream ahead by 2j draws (the reference consumes exactly two
+ *                 draws per sample, scene.c:558,598), casts its cap sample at the light, Oren-Nayar weight, shadow
+ *                 ray; then the path samples: hemisphere sample, transition hit against matter; misses take the
+ *                 background, hits become HitRecs of the next level; rays that enter the envelope of a CSG / SDF /
+ *                 compound root element are deferred to
+ *   k_hard_shadow / k_hard_path   persistent waves, one lane per deferred ray, full traversal with the CSG machine.
+ *   k_shade_hits  first step of levels >= 1: shade_hit on the stored path-sample hits; fills the ray queue of k_walk.
+ *
+ * Every kernel reads its input count from device memory (the counter block of its level) and fetches work through
+ * atomic cursors, so the host enqueues the whole chain of a chunk blind and synchronises once at its end.
+ *
+ * Queue appends: a wave reserves ACN_QCHUNK consecutive slots with one atomic and hands them out by ballot / prefix;
+ * the unused tail of an abandoned reservation is marked dead (pixel = ACN_INVALID) and skipped by the consumer.  The
+ * reservation state lives in LDS per wave, so appends may be made under divergent control flow.
  *
  * Scene access: root-compound loops run in lock-step over all lanes, so node records are fetched with wave-uniform
  * indices (scalar cache -> SGPRs); only rays that enter a CSG envelope go through the per-lane hit machine.
  *
  * Pixel accumulation is order-independent and therefore bit-reproducible: contributions are added as 2^-40
- * fixed-point integers with 64-bit integer atomics (resolution 9.1e-13, contributions clamped to +-65536, far
- * above the 1.0 at which cl_s_sat saturates).
+ * fixed-point integers with 64-bit integer atomics (resolution 9.1e-13; one contribution is clamped to +-16384 --
+ * cl_s_sat saturates at 1.0 -- and ACN_FLAG_CLAMPED reports when that happened; 2^9 clamped adds cannot wrap).
  */
 #ifndef ACN_PIPELINE_H
 #define ACN_PIPELINE_H
@@ -60,7 +73,7 @@ DEV uint64_t lcg_jump_lane( uint64_t x, int sub )
 /* ---- fixed-point pixel accumulation ---- */
 #define ACN_FIX_SCALE 1099511627776.0          /* 2^40 */
 #define ACN_FIX_INV   9.094947017729282e-13    /* 2^-40 */
-#define ACN_FIX_CLAMP 65536.0
+#define ACN_FIX_CLAMP 16384.0
 
 DEV long long to_fixed( double x )
 {
@@ -70,9 +83,11 @@ DEV long long to_fixed( double x )
     return __double2ll_rn( x * ACN_FIX_SCALE );
 }
 
-DEV void pixel_add( unsigned long long* accum, size_t i, V3 c )
+/* `flags`: the device word for ACN_FLAG_* bits; a clamped contribution is reported, not an error */
+DEV void pixel_add( unsigned long long* accum, uint32_t* flags, size_t i, V3 c )
 {
     long long x = to_fixed( c.x ), y = to_fixed( c.y ), z = to_fixed( c.z );
+    if( f_abs( c.x ) > ACN_FIX_CLAMP || f_abs( c.y ) > ACN_FIX_CLAMP || f_abs( c.z ) > ACN_FIX_CLAMP ) atomicOr( flags, ACN_FLAG_CLAMPED );
     if( x ) atomicAdd( &accum[ i * 3 + 0 ], ( unsigned long long )x );
     if( y ) atomicAdd( &accum[ i * 3 + 1 ], ( unsigned long long )y );
     if( z ) atomicAdd( &accum[ i * 3 + 2 ], ( unsigned long long )z );
@@ -87,7 +102,7 @@ struct RayTask
     V3 T;               /* colour throughput applied to whatever this ray returns */
     double intensity;
     int depth;
-    uint32_t pixel;
+    uint32_t pixel;     /* ACN_INVALID: dead slot */
 };
 
 /* a diffuse shading point whose sample loops are still to run (scene.c:526-621) */
@@ -114,7 +129,7 @@ struct HitRec
     double intensity;
     int exit_obj, enter_obj;
     int depth;
-    uint32_t pixel;
+    uint32_t pixel;      /* ACN_INVALID: dead slot */
 };
 
 /* a shadow ray of k_shade that entered the envelope of a CSG / SDF / compound element: finished by k_hard_shadow */
@@ -123,7 +138,7 @@ struct HardShadow
     V3 pos, d;
     double limit;        /* distance of the light hit */
     V3 contrib;          /* what the sample adds to the pixel if it is not occluded */
-    uint32_t pixel, pad;
+    uint32_t pixel, pad; /* pixel == ACN_INVALID: dead slot */
 };
 
 /* a path ray of k_shade that did: k_hard_path finishes the transition hit */
@@ -133,25 +148,22 @@ struct HardPath
     V3 T;
     double intensity;
     int depth;
-    uint32_t pixel;
+    uint32_t pixel;      /* ACN_INVALID: dead slot */
 };
 
+#define ACN_INVALID 0xFFFFFFFFu
 #define ACN_NCLASS 4
-enum { QC_TASKS = 0, QC_CLASS0 = 1, QC_CHILDREN = 5, QC_FLAGS = 6, QC_HARD_SHADOW = 7, QC_HARD_PATH = 8, QC_RAYS = 9, QC_CHASED = 10, QC_N = 12 };
-
-struct Queues
+/* One counter block per path level (uint32 each), all blocks of a chunk zeroed by one memset before its first launch.
+ * Queue counters are high-water marks of reserved slots (dead slots included); QS_* are exact statistics. */
+enum
 {
-    DTask*    tasks;
-    uint32_t* idx[ ACN_NCLASS ];    /* per size class: indices into tasks[] */
-    HitRec*   children;
-    HardShadow* hard_shadow;
-    HardPath*   hard_path;
-    RayTask*    rays_out;           /* specular rays spawned by this pass, traced by the next one */
-    RayTask*    loc_out;            /* k_trace_chase: the block's own next-generation queue (else nullptr) ... */
-    uint32_t*   loc_count;          /* ... its counter (LDS) and capacity; what does not fit goes to rays_out */
-    uint32_t    loc_cap;
-    uint32_t* counts;               /* QC_* */
-    uint32_t  task_cap, child_cap, hard_cap, ray_cap;
+    QC_TASKS = 0, QC_CLASS0 = 1, QC_CHILDREN = 5, QC_FLAGS = 6, QC_HARD_SHADOW = 7, QC_HARD_PATH = 8,
+    QC_RAYS = 9,        /* ray queue filled by k_shade_hits, fresh input of k_walk at levels >= 1 */
+    QC_RAYS_OVF = 10,   /* rays that did not fit a wave's private stack: input of the mop-up launch of k_walk ... */
+    QC_RAYS_OVF2 = 11,  /* ... and what did not fit there (ACN_FLAG_CHILD_OVERFLOW is raised with it) */
+    QC_CUR_WALK = 12, QC_CUR_MOP = 13, QC_CUR_HS = 14, QC_CUR_HP = 15, QC_CUR_HITS = 16,   /* work-fetch cursors */
+    QS_WALK_RAYS = 17, QS_HARD_SHADOW = 18, QS_HARD_PATH = 19, QS_CHILDREN = 20, QS_TASKS = 21, QS_WALK_STEPS = 22,
+    QC_N = 24
 };
 
 #ifndef ACN_CLASS0_MIN
@@ -163,11 +175,65 @@ DEV int size_class( uint64_t n )
     return n > ACN_CLASS0_MIN ? 0 : n > 8 ? 1 : n > 2 ? 2 : 3;
 }
 
-/* one atomic per wave: every lane with `want` gets a distinct slot */
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* Queue appends.  A wave reserves ACN_QCHUNK slots of a queue with ONE returning atomic and hands them out itself
+ * (ballot + prefix): the ~1-2 us round trip of a device-scope atomic is paid once per 64 records instead of once per
+ * append.  When a request does not fit the rest of the reservation, the rest is marked dead and a new one is taken;
+ * consumers skip dead slots.  The state ( next free slot, end ) of a wave's reservation lives in LDS, one pair per
+ * wave and queue, and is touched by one lane per append -- which makes appends legal under divergent control flow
+ * (the sample loops of k_shade): the lanes that reach an append together form its ballot. */
+#define ACN_QCHUNK 64
+struct ChunkState { uint32_t cur, end; };
+typedef ChunkState ACN_LDS* ChunkP;
+#define ACN_NCHUNKS 8     /* reservation states per wave */
+/* LDS block of the reservation states of a 256-lane workgroup; 256 B keeps the dynamic LDS behind it 16-byte aligned */
+#define ACN_CHUNK_STATES __shared__ ChunkState acn_chunk_states[ 4 * ACN_NCHUNKS ];
+#define ACN_CHUNKS_OF_WAVE ( ( ChunkP )acn_chunk_states + ( threadIdx.x >> 6 ) * ACN_NCHUNKS )
+
+DEV void chunks_init( ChunkP cs )
+{
+    if( ( threadIdx.x & 63 ) < ACN_NCHUNKS ) { cs[ threadIdx.x & 63 ].cur = 0; cs[ threadIdx.x & 63 ].end = 0; }
+}
+
+/* every lane with `want` gets a distinct slot of the queue counted by *counter; kill( k ) marks slot k dead */
+template< class KILL >
+DEV uint32_t chunk_alloc( ChunkP cs, uint32_t* counter, uint32_t cap, bool want, KILL kill )
+{
+    unsigned long long mask = __ballot( want );
+    if( !want ) return ACN_INVALID;
+    int lane = ( int )( threadIdx.x & 63 );
+    int leader = __builtin_amdgcn_readfirstlane( __ffsll( ( long long )mask ) - 1 );
+    uint32_t m = ( uint32_t )__popcll( mask );
+    uint32_t base = 0;
+    if( lane == leader )
+    {
+        uint32_t cur = cs->cur, end = cs->end;
+        if( cur + m > end )
+        {
+            for( uint32_t k = cur; k < end; k++ ) if( k < cap ) kill( k );
+            cur = atomicAdd( counter, ( uint32_t )ACN_QCHUNK );
+            cs->end = cur + ACN_QCHUNK;
+        }
+        cs->cur = cur + m;
+        base = cur;
+    }
+    base = ( uint32_t )__builtin_amdgcn_readlane( ( int )base, leader );
+    return base + ( uint32_t )__popcll( mask & ( ( 1ull << lane ) - 1ull ) );
+}
+
+/* end of a kernel (all lanes of the wave): the unused tail of the wave's last reservation is dead */
+template< class KILL >
+DEV void chunk_close( ChunkP cs, uint32_t cap, KILL kill )
+{
+    uint32_t cur = cs->cur, end = cs->end;
+    for( uint32_t k = cur + ( threadIdx.x & 63 ); k < end; k += 64 ) if( k < cap ) kill( k );
+}
+
+/* one atomic per wave: every lane with `want` gets a distinct slot (unreserved form, used where appends are rare) */
 DEV uint32_t wave_alloc( uint32_t* counter, bool want )
 {
     unsigned long long mask = __ballot( want );
-    if( !want ) return 0xFFFFFFFFu;
+    if( !want ) return ACN_INVALID;
     int lane = ( int )( threadIdx.x & 63 );
     int leader = __builtin_amdgcn_readfirstlane( __ffsll( ( long long )mask ) - 1 );
     uint32_t base = 0;
@@ -176,43 +242,97 @@ DEV uint32_t wave_alloc( uint32_t* counter, bool want )
     return base + ( uint32_t )__popcll( mask & ( ( 1ull << lane ) - 1ull ) );
 }
 
-/* ------------------------------------------------------------------------------------------------------------------ */
-/* scene_s_lum for one hit, everything except the two sample loops (scene.c:420-537, 623-664).  Specular children
- * (Fresnel reflection, chromatic reflection, refraction) are appended to the ray queue of the next pass; the diffuse
- * block becomes a DTask. */
-DEV void push_ray( const Queues& q, bool want, V3 p, V3 d, V3 T, double intensity, int depth, uint32_t pixel )
+DEV void wave_stat_add( uint32_t* counter, uint32_t v )   /* all lanes of the wave */
 {
-    if( q.loc_out )   /* block-local queue of k_trace_chase (wave-uniform branch) */
-    {
-        uint32_t ls = wave_alloc( q.loc_count, want );
-        if( want && ls < q.loc_cap )
-        {
-            RayTask& c = q.loc_out[ ls ];
-            c.p = p; c.d = d; c.T = T; c.intensity = intensity; c.depth = depth; c.pixel = pixel;
-        }
-        want = want && ls >= q.loc_cap;   /* overflow of the local queue: the ray joins the next ordinary pass */
-    }
-    uint32_t slot = wave_alloc( &q.counts[ QC_RAYS ], want );
-    if( want )
-    {
-        if( slot < q.ray_cap )
-        {
-            RayTask& c = q.rays_out[ slot ];
-            c.p = p; c.d = d; c.T = T; c.intensity = intensity; c.depth = depth; c.pixel = pixel;
-        }
-        else
-        {
-            atomicOr( &q.counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
-        }
-    }
+    for( int o = 32; o > 0; o >>= 1 ) v += __shfl_down( v, o, 64 );
+    if( ( threadIdx.x & 63 ) == 0 && v ) atomicAdd( counter, v );
 }
 
-template< class CT >
-DEV void shade_hit( const DevScene& sc, const Queues& q, V3 rp, V3 rd, double offs, const Trans& trans, int depth,
+/* work fetch of the persistent kernels: the wave takes the next `want` items of [ 0, n ); returns how many it got */
+DEV uint32_t wave_fetch( uint32_t* cursor, uint32_t want, uint32_t n, uint32_t* first )
+{
+    uint32_t b = 0;
+    if( ( threadIdx.x & 63 ) == 0 ) b = atomicAdd( cursor, want );
+    b = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )b );
+    *first = b;
+    if( b >= n ) return 0;
+    return n - b < want ? n - b : want;
+}
+
+/* ---- where shade_hit puts what it produces ---- */
+
+/* the queues of diffuse shading tasks: tasks[] + one index list per size class */
+struct TaskQ
+{
+    DTask*    tasks;
+    uint32_t* idx[ ACN_NCLASS ];
+    uint32_t* counts;               /* counter block of the level */
+    uint32_t  task_cap;
+};
+
+/* a ray queue in global memory (k_shade_hits -> k_walk; private-stack overflow of k_walk) */
+struct RayQ
+{
+    RayTask*  rays;
+    uint32_t* counter;
+    uint32_t  cap;
+    uint32_t* flags;
+    ChunkP    cs;
+
+    DEV void push( bool want, V3 p, V3 d, V3 T, double intensity, int depth, uint32_t pixel ) const
+    {
+        RayTask* r = rays;
+        uint32_t slot = chunk_alloc( cs, counter, cap, want, [ r ]( uint32_t k ) { r[ k ].pixel = ACN_INVALID; } );
+        if( want )
+        {
+            if( slot < cap )
+            {
+                RayTask& c = rays[ slot ];
+                c.p = p; c.d = d; c.T = T; c.intensity = intensity; c.depth = depth; c.pixel = pixel;
+            }
+            else atomicOr( flags, ACN_FLAG_CHILD_OVERFLOW );
+        }
+    }
+    DEV void close() const
+    {
+        RayTask* r = rays;
+        chunk_close( cs, cap, [ r ]( uint32_t k ) { r[ k ].pixel = ACN_INVALID; } );
+    }
+};
+
+/* the private LIFO stack of a k_walk wave; `top` is the same in all lanes (every lane of the wave calls push) */
+struct RayStack
+{
+    RayTask*  stack;
+    uint32_t  cap;
+    uint32_t  top;
+    RayQ      ovf;       /* what does not fit goes to the mop-up launch */
+
+    DEV void push( bool want, V3 p, V3 d, V3 T, double intensity, int depth, uint32_t pixel )
+    {
+        unsigned long long mask = __ballot( want );
+        uint32_t slot = top + ( uint32_t )__popcll( mask & ( ( 1ull << ( threadIdx.x & 63 ) ) - 1ull ) );
+        uint32_t new_top = top + ( uint32_t )__popcll( mask );
+        bool fits = slot < cap;
+        if( want && fits )
+        {
+            RayTask& c = stack[ slot ];
+            c.p = p; c.d = d; c.T = T; c.intensity = intensity; c.depth = depth; c.pixel = pixel;
+        }
+        top = new_top < cap ? new_top : cap;
+        if( new_top > cap ) ovf.push( want && !fits, p, d, T, intensity, depth, pixel );   /* wave-uniform branch */
+    }
+};
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* scene_s_lum for one hit, everything except the two sample loops (scene.c:420-537, 623-664).  Specular children
+ * (Fresnel reflection, chromatic reflection, refraction) are pushed to `rays`; the diffuse block becomes a DTask.
+ * Every lane of the wave must call this (the appends are wave-wide); lanes with nothing to shade pass depth 0. */
+template< class RAYS, class CT >
+DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs, V3 rp, V3 rd, double offs, const Trans& trans, int depth,
                     double intensity, V3 T, uint32_t pixel, V3& acc, CT* cnt )
 {
     const double min_intensity = sc.prm.trace_min_intensity;
-    /* every lane takes part in the queue appends below; `go` masks the ones with nothing to shade */
     bool go = !( depth == 0 || intensity < min_intensity );
     if( go ) cnt->inc( CNT_LUM );
     V3 pos = ray_pos( rp, rd, offs );
@@ -269,7 +389,7 @@ DEV void shade_hit( const DevScene& sc, const Queues& q, V3 rp, V3 rd, double of
         V3 out_d = rd;
         double reflectance = 0;
         if( f ) reflectance = fresnel_reflection( rd, trans.exit_nor, trix, &out_d ) * fresnel_reflectivity;
-        push_ray( q, f, pos, out_d, T, reflectance * intensity, depth - 1, pixel );
+        rays.push( f, pos, out_d, T, reflectance * intensity, depth - 1, pixel );
         if( f ) intensity *= ( 1.0 - reflectance );
     }
 
@@ -278,7 +398,7 @@ DEV void shade_hit( const DevScene& sc, const Queues& q, V3 rp, V3 rd, double of
         bool f = go && chromatic_reflectivity > 0 && intensity >= min_intensity;
         V3 out_d = rd;
         if( f ) out_d = v_reflection( rd, trans.exit_nor );
-        push_ray( q, f, pos, out_d, v_mld( T, enter_color ), chromatic_reflectivity * intensity, depth - 1, pixel );
+        rays.push( f, pos, out_d, v_mld( T, enter_color ), chromatic_reflectivity * intensity, depth - 1, pixel );
         if( f ) intensity *= ( 1.0 - chromatic_reflectivity );
     }
 
@@ -301,13 +421,14 @@ DEV void shade_hit( const DevScene& sc, const Queues& q, V3 rp, V3 rd, double of
     }
     bool emit = diffuse && ( n_direct | n_path ) != 0;
     {
-        uint32_t slot = wave_alloc( &q.counts[ QC_TASKS ], emit );
-        bool ok = emit && slot < q.task_cap;
-        if( emit && !ok ) atomicOr( &q.counts[ QC_FLAGS ], ACN_FLAG_TASK_OVERFLOW );
+        /* task slots need no dead marks: tasks are only reached through the index lists */
+        uint32_t slot = chunk_alloc( tcs, &tq.counts[ QC_TASKS ], tq.task_cap, emit, []( uint32_t ) {} );
+        bool ok = emit && slot < tq.task_cap;
+        if( emit && !ok ) atomicOr( &tq.counts[ QC_FLAGS ], ACN_FLAG_TASK_OVERFLOW );
         int cls = ok ? size_class( n_direct > n_path ? n_direct : n_path ) : -1;
         if( ok )
         {
-            DTask& t = q.tasks[ slot ];
+            DTask& t = tq.tasks[ slot ];
             V3 surface_d = v_neg( trans.exit_nor );
             t.pos = pos;
             t.surface_d = surface_d;
@@ -322,8 +443,13 @@ DEV void shade_hit( const DevScene& sc, const Queues& q, V3 rp, V3 rd, double of
         }
         for( int k = 0; k < ACN_NCLASS; k++ )
         {
-            uint32_t is = wave_alloc( &q.counts[ QC_CLASS0 + k ], cls == k );
-            if( cls == k ) q.idx[ k ][ is ] = slot;
+            uint32_t* list = tq.idx[ k ];
+            uint32_t is = chunk_alloc( tcs + 1 + k, &tq.counts[ QC_CLASS0 + k ], tq.task_cap, cls == k, [ list ]( uint32_t j ) { list[ j ] = ACN_INVALID; } );
+            if( cls == k )
+            {
+                if( is < tq.task_cap ) list[ is ] = slot;
+                else atomicOr( &tq.counts[ QC_FLAGS ], ACN_FLAG_TASK_OVERFLOW );
+            }
         }
     }
     if( diffuse ) intensity *= ( 1.0 - diffuse_reflectivity );
@@ -333,7 +459,17 @@ DEV void shade_hit( const DevScene& sc, const Queues& q, V3 rp, V3 rd, double of
         bool f = go && transparent && intensity >= min_intensity;
         V3 out_d = rd;
         if( f ) out_d = fresnel_refraction( rd, trans.exit_nor, trix );
-        push_ray( q, f, ray_pos( rp, rd, offs + 2.0 * F3_EPS ), out_d, T, intensity, depth - 1, pixel );
+        rays.push( f, ray_pos( rp, rd, offs + 2.0 * F3_EPS ), out_d, T, intensity, depth - 1, pixel );
+    }
+}
+
+/* the index lists' reservations of a wave end with the kernel */
+DEV void task_chunks_close( const TaskQ& tq, ChunkP tcs )
+{
+    for( int k = 0; k < ACN_NCLASS; k++ )
+    {
+        uint32_t* list = tq.idx[ k ];
+        chunk_close( tcs + 1 + k, tq.task_cap, [ list ]( uint32_t j ) { list[ j ] = ACN_INVALID; } );
     }
 }
 
@@ -354,10 +490,10 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
 #ifndef ACN_WALK_WAVES
 #define ACN_WALK_WAVES 4
 #endif
-/* Kernel parameter convention: every buffer is passed as its own __restrict__ pointer and the DevScene / Queues views
- * are rebuilt inside (scene arrays are then read through the constant address space, see acn_device.h). */
+/* Kernel parameter convention: every scene buffer is passed as its own __restrict__ pointer and the DevScene view is
+ * rebuilt inside (scene arrays are then read through the constant address space, see acn_device.h); p_counts is the
+ * counter block of the kernel's level. */
 #define ACN_SCENE_PARAMS  DevScene sc_in, const GNode* __restrict__ p_nodes, const GMat* __restrict__ p_mats, const int32_t* __restrict__ p_elems, const acn_texture* __restrict__ p_textures
-#define ACN_SCENE_ARGS( h ) ( h )->dev, ( h )->d_nodes, ( h )->d_mats, ( h )->d_elems, ( h )->d_textures
 #define ACN_SCENE_VIEW    DevScene sc = sc_in; sc.nodes = ( NodeP )p_nodes; sc.mats = ( MatP )p_mats; sc.elems = ( ElemP )p_elems; sc.textures = ( TexP )p_textures; sc.flags = p_counts + QC_FLAGS; sc.lds_stack = ACN_NO_LDS_STACK;
 
 /* LDS staging of the node array (kernels whose node reads are per-lane: the CSG machines).  The block copies the
@@ -370,75 +506,12 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
         __syncthreads(); \
     }
 
-#define ACN_WALK_QUEUE_PARAMS DTask* __restrict__ p_tasks, uint32_t* __restrict__ p_idx0, uint32_t* __restrict__ p_idx1, \
-    uint32_t* __restrict__ p_idx2, uint32_t* __restrict__ p_idx3, uint32_t* __restrict__ p_counts, uint32_t task_cap, \
-    RayTask* __restrict__ p_rays_out, uint32_t ray_cap
-#define ACN_WALK_QUEUE_VIEW \
-    Queues q; \
-    q.tasks = p_tasks; q.idx[ 0 ] = p_idx0; q.idx[ 1 ] = p_idx1; q.idx[ 2 ] = p_idx2; q.idx[ 3 ] = p_idx3; \
-    q.children = nullptr; q.counts = p_counts; q.task_cap = task_cap; q.child_cap = 0; \
-    q.hard_shadow = nullptr; q.hard_path = nullptr; q.hard_cap = 0; q.rays_out = p_rays_out; q.ray_cap = ray_cap; \
-    q.loc_out = nullptr; q.loc_count = nullptr; q.loc_cap = 0;
-
-/* one ray: scene_s_trans_hit, then the hit is shaded; what it spawns goes to the queues.  Every lane of a wave must call
- * this (the queue appends are wave-wide); lanes without a ray pass live = false. */
-template< class SCL, class CT >
-DEV void trace_one( const DevScene& sc, const SCL& scl, const Queues& q, const RayTask& t, bool live,
-                    unsigned long long* __restrict__ accum, CT* cnt )
-{
-    V3 acc = mk( 0, 0, 0 );
-    Trans trans;
-    trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
-    double offs = F3_INF;
-    if( live ) offs = scene_trans_hit_dev( scl, t.p, t.d, &trans, cnt );
-    bool hit = live && offs < F3_INF;
-    if( live && !hit )
-    {
-        V3 c = v_mlf( ld3( sc.prm.background_color ), t.intensity );
-        acc = v_mld( t.T, c );
-    }
-    shade_hit( sc, q, t.p, t.d, hit ? offs : 0.0, trans, hit ? t.depth : 0, t.intensity, t.T, t.pixel, acc, cnt );
-    if( live ) pixel_add( accum, t.pixel, acc );
-}
-
-/* One pass of the specular walk: one lane per ray.  rays_in == nullptr: the rays are the camera rays of the sample positions
- * (lum_machine_s_func, scene.c:976-1011); otherwise they come from the ray queue the previous pass filled.  Each ray
- * is traced (scene_s_trans_hit) and its hit shaded; what it spawns goes to the next pass / the shading-task queues. */
-template< bool COUNT, class SCL >
-DEV void trace_rays_body( const DevScene& sc, const SCL& scl, const Queues& q, const RayTask* __restrict__ rays_in,
-                          const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n,
-                          unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    Cnt< COUNT > cnt;
-    cnt.clear();
-    bool live = i < n;
-    RayTask t;
-    t.p = mk( 0, 0, 0 ); t.d = mk( 0, 0, 1 ); t.T = mk( 0, 0, 0 ); t.intensity = 0; t.depth = 0; t.pixel = 0;
-    if( live )
-    {
-        if( !rays_in )   /* the camera rays of the sample positions (wave-uniform branch) */
-        {
-            uint32_t pixel = base + i;
-            double mx, my;
-            if( pos_xy ) { mx = pos_xy[ ( size_t )pixel * 2 ]; my = pos_xy[ ( size_t )pixel * 2 + 1 ]; }
-            else
-            {
-                size_t pix = first_pixel + pixel;
-                mx = ( double )( pix % sc.prm.image_width ) + 0.5;
-                my = ( double )( pix / sc.prm.image_width ) + 0.5;
-            }
-            camera_ray( sc, mx, my, &t.p, &t.d );
-            t.T = mk( 1, 1, 1 ); t.intensity = 1.0; t.depth = ( int )sc.prm.trace_depth; t.pixel = pixel;
-        }
-        else
-        {
-            t = rays_in[ i ];
-        }
-    }
-    trace_one( sc, scl, q, t, live, accum, &cnt );
-    wave_add_counters( counters, cnt );
-}
+#define ACN_TASKQ_PARAMS DTask* __restrict__ p_tasks, uint32_t* __restrict__ p_idx0, uint32_t* __restrict__ p_idx1, \
+    uint32_t* __restrict__ p_idx2, uint32_t* __restrict__ p_idx3, uint32_t* __restrict__ p_counts, uint32_t task_cap
+#define ACN_TASKQ_VIEW \
+    TaskQ tq; \
+    tq.tasks = p_tasks; tq.idx[ 0 ] = p_idx0; tq.idx[ 1 ] = p_idx1; tq.idx[ 2 ] = p_idx2; tq.idx[ 3 ] = p_idx3; \
+    tq.counts = p_counts; tq.task_cap = task_cap;
 
 #ifndef ACN_TRACE_WAVES
 #define ACN_TRACE_WAVES ACN_WALK_WAVES
@@ -446,112 +519,158 @@ DEV void trace_rays_body( const DevScene& sc, const SCL& scl, const Queues& q, c
 #ifndef ACN_HPATH_WAVES
 #define ACN_HPATH_WAVES ACN_WALK_WAVES
 #endif
-template< bool COUNT, bool LDS, bool PRUNE >
-__global__ __launch_bounds__( 256, ACN_TRACE_WAVES )
-void k_trace_rays( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __restrict__ rays_in,
-                   const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n,
-                   unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
-{
-    ACN_SCENE_VIEW
-    ACN_WALK_QUEUE_VIEW
-    if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
-    if constexpr( LDS )
-    {
-        ACN_STAGE_NODES( sc )
-        trace_rays_body< COUNT >( sc, scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), q, rays_in, pos_xy, first_pixel, base, n, accum, counters );
-    }
-    else
-    {
-        trace_rays_body< COUNT >( sc, scene_view< PRUNE >( sc, sc.nodes ), q, rays_in, pos_xy, first_pixel, base, n, accum, counters );
-    }
-}
+#ifndef ACN_WALK_MAX_STEPS
+#define ACN_WALK_MAX_STEPS ( 1u << 20 )   /* safety bound of a wave's step loop (64 M rays per wave) */
+#endif
 
-/* The tail of the specular walk in ONE launch.  Late generations hold few rays, but every generation is a launch plus a
- * host round trip, and a level has ~40 of them: on the share of a frame that one of 8 GPUs renders the chain of
- * launches, not the work, sets the time.  Once a generation is small (ACN_CHASE_MAX rays) each block takes 256 of its
- * rays and follows THEIR descendants by itself: children go to a block-private queue (two ping-pong regions of
- * ACN_CHASE_CAP rays in global memory, counter in LDS) and are traced by the same block in the next round.  No block
- * waits for another one, every loop is bounded (ACN_CHASE_ROUNDS), and whatever does not fit the private queue or is
- * left after the last round goes to the ordinary ray queue for an ordinary pass -- so the kernel cannot hang and never
- * loses a ray.  Per ray the computation is the one of k_trace_rays; only the order of queue entries differs, which the
- * results do not depend on. */
-#define ACN_CHASE_CAP    2048
-#define ACN_CHASE_ROUNDS 64
+/* The specular walk of one path level in ONE launch of persistent waves (see the head of this file).
+ * Fresh input: rays_in == nullptr: the camera rays of sample positions [ base, base + n_cam ) of the call
+ * (lum_machine_s_func, scene.c:976-1011); else the ray queue rays_in[ 0 .. min( *n_in_ptr, in_cap ) ).
+ * cur_slot / ovf_slot: indices into the level's counter block of the fetch cursor and of the overflow queue's counter.
+ * stacks: ( waves of the grid ) x stack_stride private ray slots, of which a wave uses stack_cap. */
 template< bool COUNT, bool LDS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_TRACE_WAVES )
-void k_trace_chase( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const RayTask* __restrict__ rays_in, uint32_t n,
-                    RayTask* __restrict__ chase_buf, unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
+void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ rays_in, const uint32_t* __restrict__ n_in_ptr, uint32_t in_cap,
+             const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n_cam,
+             uint32_t cur_slot, uint32_t ovf_slot, RayTask* __restrict__ ovf_rays, uint32_t ovf_cap,
+             RayTask* __restrict__ stacks, uint32_t stack_stride, uint32_t stack_cap,
+             unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
+    ACN_CHUNK_STATES
     ACN_SCENE_VIEW
-    ACN_WALK_QUEUE_VIEW
-    if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;
+    ACN_TASKQ_VIEW
+    if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
     if constexpr( LDS ) ACN_STAGE_NODES( sc )
-    __shared__ uint32_t loc_n[ 2 ];
+    const ChunkP cs = ACN_CHUNKS_OF_WAVE;
+    chunks_init( cs );
     Cnt< COUNT > cnt;
     cnt.clear();
-    RayTask* region[ 2 ] = { chase_buf + ( size_t )blockIdx.x * 2 * ACN_CHASE_CAP, chase_buf + ( ( size_t )blockIdx.x * 2 + 1 ) * ACN_CHASE_CAP };
-    q.loc_cap = ACN_CHASE_CAP;
-    uint32_t traced = 0;
-    /* round 0 reads the block's 256 rays of the input generation, round r > 0 the private queue round r - 1 filled */
-    const RayTask* in = rays_in + ( size_t )blockIdx.x * blockDim.x;
-    uint32_t first = blockIdx.x * blockDim.x;
-    uint32_t n_loc = first < n ? ( n - first < blockDim.x ? n - first : blockDim.x ) : 0;
-    for( int round = 0; round <= ACN_CHASE_ROUNDS && n_loc > 0; round++ )
+    const int lane = ( int )( threadIdx.x & 63 );
+    const uint32_t wave = blockIdx.x * ( blockDim.x >> 6 ) + ( threadIdx.x >> 6 );
+    uint32_t n_in = n_cam;
+    if( rays_in ) { n_in = *n_in_ptr; n_in = n_in < in_cap ? n_in : in_cap; }
+    n_in = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n_in );
+    RayStack st;
+    st.stack = stacks + ( size_t )wave * stack_stride; st.cap = stack_cap; st.top = 0;
+    st.ovf.rays = ovf_rays; st.ovf.counter = p_counts + ovf_slot; st.ovf.cap = ovf_cap; st.ovf.flags = p_counts + QC_FLAGS; st.ovf.cs = cs + 5;
+    uint32_t* cursor = p_counts + cur_slot;
+    bool more = n_in > 0;
+    uint32_t traced = 0, steps = 0;
+    bool finished = false;
+    for( uint32_t step = 0; step < ACN_WALK_MAX_STEPS; step++ )
     {
-        const int o = round & 1;
-        const bool last = round == ACN_CHASE_ROUNDS;    /* the last round only hands what is left to the ordinary queue */
-        if( threadIdx.x == 0 ) loc_n[ o ] = 0;
-        __syncthreads();
-        q.loc_out = last ? nullptr : region[ o ];
-        q.loc_count = &loc_n[ o ];
-        for( uint32_t j0 = 0; j0 < n_loc; j0 += blockDim.x )
+        /* the step's 64 rays: the top of the private stack, topped up with fresh input */
+        uint32_t n_pop = st.top < 64u ? st.top : 64u;
+        uint32_t n_fresh = 0, fb = 0;
+        if( more && n_pop < 64u )
         {
-            uint32_t j = j0 + threadIdx.x;
-            bool live = j < n_loc;
-            RayTask t;
-            t.p = mk( 0, 0, 0 ); t.d = mk( 0, 0, 1 ); t.T = mk( 0, 0, 0 ); t.intensity = 0; t.depth = 0; t.pixel = 0;
-            if( live ) t = in[ j ];
-            if( last ) push_ray( q, live, t.p, t.d, t.T, t.intensity, t.depth, t.pixel );
+            n_fresh = wave_fetch( cursor, 64u - n_pop, n_in, &fb );
+            if( fb + ( 64u - n_pop ) >= n_in ) more = false;
+        }
+        if( n_pop + n_fresh == 0 ) { finished = true; break; }
+        st.top -= n_pop;
+        const RayTask* src = nullptr;
+        bool live = false;
+        uint32_t pixel = 0;
+        V3 rp = mk( 0, 0, 0 ), rd = mk( 0, 0, 1 );
+        if( ( uint32_t )lane < n_pop ) { src = st.stack + st.top + lane; live = true; }
+        else if( ( uint32_t )lane < n_pop + n_fresh )
+        {
+            uint32_t i = fb + ( ( uint32_t )lane - n_pop );
+            if( rays_in ) { src = rays_in + i; live = src->pixel != ACN_INVALID; }
             else
             {
-                if( live ) traced++;
-                if constexpr( LDS ) trace_one( sc, scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), q, t, live, accum, &cnt );
-                else                trace_one( sc, scene_view< PRUNE >( sc, sc.nodes ), q, t, live, accum, &cnt );
+                /* the camera ray of a sample position */
+                pixel = base + i;
+                double mx, my;
+                if( pos_xy ) { mx = pos_xy[ ( size_t )pixel * 2 ]; my = pos_xy[ ( size_t )pixel * 2 + 1 ]; }
+                else
+                {
+                    size_t pix = first_pixel + pixel;
+                    mx = ( double )( pix % sc.prm.image_width ) + 0.5;
+                    my = ( double )( pix / sc.prm.image_width ) + 0.5;
+                }
+                camera_ray( sc, mx, my, &rp, &rd );
+                live = true;
             }
         }
-        __syncthreads();
-        n_loc = last ? 0 : loc_n[ o ];
-        if( n_loc > ACN_CHASE_CAP ) n_loc = ACN_CHASE_CAP;   /* the excess went to the ordinary queue */
-        in = region[ o ];
-        __syncthreads();   /* loc_n[ o ] is read by everyone before the round after next resets it */
+        if( src && live ) { rp = src->p; rd = src->d; }
+        if( live ) traced++;
+        steps++;
+
+        /* scene_s_trans_hit */
+        Trans trans;
+        trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
+        double offs = F3_INF;
+        if( live )
+        {
+            if constexpr( LDS ) offs = scene_trans_hit_dev( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), rp, rd, &trans, &cnt );
+            else                offs = scene_trans_hit_dev( scene_view< PRUNE >( sc, sc.nodes ), rp, rd, &trans, &cnt );
+        }
+        /* what the ray carries is read only now, so that it does not occupy registers across the traversal */
+        asm volatile( "" ::: "memory" );
+        V3 T = mk( 1, 1, 1 );
+        double intensity = 1.0;
+        int depth = ( int )sc.prm.trace_depth;
+        if( src && live ) { T = src->T; intensity = src->intensity; depth = src->depth; pixel = src->pixel; }
+        bool hit = live && offs < F3_INF;
+        V3 acc = mk( 0, 0, 0 );
+        if( live && !hit ) acc = v_mld( T, v_mlf( ld3( sc.prm.background_color ), intensity ) );
+        shade_hit( sc, st, tq, cs, rp, rd, hit ? offs : 0.0, trans, hit ? depth : 0, intensity, T, pixel, acc, &cnt );
+        if( live ) pixel_add( accum, sc.flags, pixel, acc );
+        /* the wave reads next what it wrote last: same wave, program order; the fence keeps the compiler from moving the
+         * next step's loads above this step's stores */
+        __builtin_amdgcn_fence( __ATOMIC_SEQ_CST, "wavefront" );
     }
-    /* statistics: rays traced here */
-    for( int o = 32; o > 0; o >>= 1 ) traced += __shfl_down( traced, o );
-    if( ( threadIdx.x & 63 ) == 0 && traced ) atomicAdd( &p_counts[ QC_CHASED ], traced );
+    /* the step bound is a safety net against a loop that does not end; work would be lost, so the call fails */
+    if( !finished && lane == 0 ) atomicOr( p_counts + QC_FLAGS, ACN_FLAG_STACK_OVERFLOW );
+    st.ovf.close();
+    task_chunks_close( tq, cs );
+    wave_stat_add( p_counts + QS_WALK_RAYS, traced );
+    if( lane == 0 && steps ) atomicAdd( p_counts + QS_WALK_STEPS, steps );
     wave_add_counters( counters, cnt );
 }
 
-/* first pass of a level >= 1: one lane per path-sample hit (the recursive scene_s_lum call of scene.c:610) */
+/* first step of a level >= 1: one lane per path-sample hit of the previous level (the recursive scene_s_lum call of
+ * scene.c:610); persistent waves fetch 64 records at a time.  n_ptr: the previous level's QC_CHILDREN. */
 template< bool COUNT >
 __global__ __launch_bounds__( 256, ACN_WALK_WAVES )
-void k_shade_hits( ACN_SCENE_PARAMS, ACN_WALK_QUEUE_PARAMS, const HitRec* __restrict__ recs, uint32_t n,
+void k_shade_hits( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const HitRec* __restrict__ recs, const uint32_t* __restrict__ n_ptr, uint32_t rec_cap,
+                   RayTask* __restrict__ rays_out, uint32_t ray_cap,
                    unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
+    ACN_CHUNK_STATES
     ACN_SCENE_VIEW
-    ACN_WALK_QUEUE_VIEW
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    ACN_TASKQ_VIEW
+    const ChunkP cs = ACN_CHUNKS_OF_WAVE;
+    chunks_init( cs );
     Cnt< COUNT > cnt;
     cnt.clear();
-    bool live = i < n;
-    HitRec r;
-    r.p = mk( 0, 0, 0 ); r.d = mk( 0, 0, 1 ); r.offs = 0; r.exit_nor = mk( 0, 0, 0 ); r.T = mk( 0, 0, 0 ); r.intensity = 0;
-    r.exit_obj = -1; r.enter_obj = -1; r.depth = 0; r.pixel = 0;
-    if( live ) r = recs[ i ];
-    V3 acc = mk( 0, 0, 0 );
-    Trans trans;
-    trans.exit_nor = r.exit_nor; trans.exit_obj = r.exit_obj; trans.enter_obj = r.enter_obj;
-    shade_hit( sc, q, r.p, r.d, r.offs, trans, r.depth, r.intensity, r.T, r.pixel, acc, &cnt );
-    if( live ) pixel_add( accum, r.pixel, acc );
+    uint32_t n = *n_ptr;
+    n = n < rec_cap ? n : rec_cap;
+    n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
+    RayQ rq;
+    rq.rays = rays_out; rq.counter = p_counts + QC_RAYS; rq.cap = ray_cap; rq.flags = p_counts + QC_FLAGS; rq.cs = cs + 5;
+    for( ;; )
+    {
+        uint32_t first = 0;
+        uint32_t got = wave_fetch( p_counts + QC_CUR_HITS, 64u, n, &first );
+        if( got == 0 ) break;
+        uint32_t i = first + ( threadIdx.x & 63 );
+        bool live = ( threadIdx.x & 63 ) < got;
+        HitRec r;
+        r.p = mk( 0, 0, 0 ); r.d = mk( 0, 0, 1 ); r.offs = 0; r.exit_nor = mk( 0, 0, 0 ); r.T = mk( 0, 0, 0 ); r.intensity = 0;
+        r.exit_obj = -1; r.enter_obj = -1; r.depth = 0; r.pixel = ACN_INVALID;
+        if( live ) r = recs[ i ];
+        live = live && r.pixel != ACN_INVALID;
+        V3 acc = mk( 0, 0, 0 );
+        Trans trans;
+        trans.exit_nor = r.exit_nor; trans.exit_obj = r.exit_obj; trans.enter_obj = r.enter_obj;
+        shade_hit( sc, rq, tq, cs, r.p, r.d, r.offs, trans, live ? r.depth : 0, r.intensity, r.T, r.pixel, acc, &cnt );
+        if( live ) pixel_add( accum, sc.flags, r.pixel, acc );
+    }
+    rq.close();
+    task_chunks_close( tq, cs );
     wave_add_counters( counters, cnt );
 }
 
@@ -573,20 +692,21 @@ template< int LPT > DEV uint64_t lcg_stride( uint64_t x )   /* jump by 2*LPT dra
 }
 
 /* LEAF_LIGHTS: every light is a plane / sphere / squaroid-free leaf, so the kernel contains no call into the CSG
- * machine at all (the usual case); otherwise the light hit goes through the generic element test. */
+ * machine at all (the usual case); otherwise the light hit goes through the generic element test.
+ * The tasks are idx[ 0 .. min( p_counts[ QC_CLASS0 + cls ], task_cap ) ) (dead entries skipped), dealt to the waves
+ * of the grid in strides. */
 template< int LPT, bool COUNT, bool LEAF_LIGHTS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_SHADE_WAVES )
-void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t* __restrict__ idx, uint32_t n_tasks,
+void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t* __restrict__ idx, int cls, uint32_t task_cap,
               HitRec* __restrict__ p_children, uint32_t child_cap, HardShadow* __restrict__ p_hard_shadow,
               HardPath* __restrict__ p_hard_path, uint32_t hard_cap, uint32_t* __restrict__ p_counts,
               unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
+    ACN_CHUNK_STATES
     ACN_SCENE_VIEW
     const auto scp = scene_view< PRUNE >( sc, sc.nodes );   /* the scene as the two root-traversal fast paths see it */
-    Queues q;
-    q.tasks = nullptr; q.children = p_children; q.counts = p_counts; q.task_cap = 0; q.child_cap = child_cap;
-    q.hard_shadow = p_hard_shadow; q.hard_path = p_hard_path; q.hard_cap = hard_cap; q.rays_out = nullptr; q.ray_cap = 0;
-    q.loc_out = nullptr; q.loc_count = nullptr; q.loc_cap = 0;
+    const ChunkP cs = ACN_CHUNKS_OF_WAVE;                   /* [0] hard shadow, [1] hard path, [2] children */
+    chunks_init( cs );
     constexpr int G = 64 / LPT;
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPT;
@@ -596,6 +716,13 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
     Cnt< COUNT > cnt;
     cnt.clear();
     const V3 bg = ld3( sc.prm.background_color );
+    uint32_t n_tasks = p_counts[ QC_CLASS0 + cls ];
+    n_tasks = n_tasks < task_cap ? n_tasks : task_cap;
+    n_tasks = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n_tasks );
+    uint32_t n_hs = 0, n_hp = 0, n_ch = 0;   /* statistics: records written by this lane */
+    auto kill_hs = [ p_hard_shadow ]( uint32_t k ) { p_hard_shadow[ k ].pixel = ACN_INVALID; };
+    auto kill_hp = [ p_hard_path ]( uint32_t k ) { p_hard_path[ k ].pixel = ACN_INVALID; };
+    auto kill_ch = [ p_children ]( uint32_t k ) { p_children[ k ].pixel = ACN_INVALID; };
 
     for( uint32_t base = wave * G; base < n_tasks; base += n_waves * G )
     {
@@ -603,6 +730,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
         if( ti >= n_tasks ) continue;
         uint32_t slot = ( ( ElemP )( const void* )idx )[ ti ];
         if( LPT == 64 ) slot = __builtin_amdgcn_readfirstlane( slot );
+        if( slot == ACN_INVALID ) continue;
         const DTask ACN_CONST& t = ( ( const DTask ACN_CONST* )tasks )[ slot ];
         const V3 pos = ldc( t.pos ), surface_d = ldc( t.surface_d ), ray_projection = ldc( t.ray_projection );
         const double theta_i = t.theta_i, on_a = t.on_a, on_b = t.on_b, diffuse_intensity = t.diffuse_intensity;
@@ -651,22 +779,23 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 double c = local_intensity * weight * diffuse_intensity;
                 int occ = root_occluded_fast( scp, sc.matter_root, pos, out_d, a, &cnt );
                 if( occ == 0 ) s += c;
-                /* hard shadow rays: compacted into the queue of k_hard_shadow, which adds c itself if unoccluded */
-                uint32_t hs = wave_alloc( &q.counts[ QC_HARD_SHADOW ], occ == 2 );
+                /* hard shadow rays: appended to the queue of k_hard_shadow, which adds c itself if unoccluded */
+                uint32_t hs = chunk_alloc( cs + 0, &p_counts[ QC_HARD_SHADOW ], hard_cap, occ == 2, kill_hs );
                 if( occ == 2 )
                 {
-                    if( hs < q.hard_cap )
+                    if( hs < hard_cap )
                     {
-                        HardShadow& h = q.hard_shadow[ hs ];
+                        HardShadow& h = p_hard_shadow[ hs ];
                         double f = c * ( 2.0 * cyl_hgt / direct_samples );
                         V3 Tc = ldc( t.Tc );
                         h.pos = pos; h.d = out_d; h.limit = a;
                         h.contrib = mk( Tc.x * ( light_color.x * f ), Tc.y * ( light_color.y * f ), Tc.z * ( light_color.z * f ) );
                         h.pixel = t.pixel; h.pad = 0;
+                        n_hs++;
                     }
                     else
                     {
-                        atomicOr( &q.counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+                        atomicOr( &p_counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
                     }
                 }
             }
@@ -706,35 +835,37 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 bool hit = live && !hard && a < sc.prm.max_path_length;
                 if( live && !hard && !hit ) bsum += weight * diffuse_intensity;
                 /* hard path rays: the transition hit is finished by k_hard_path */
-                uint32_t hp = wave_alloc( &q.counts[ QC_HARD_PATH ], hard );
+                uint32_t hp = chunk_alloc( cs + 1, &p_counts[ QC_HARD_PATH ], hard_cap, hard, kill_hp );
                 if( hard )
                 {
-                    if( hp < q.hard_cap )
+                    if( hp < hard_cap )
                     {
-                        HardPath& h = q.hard_path[ hp ];
+                        HardPath& h = p_hard_path[ hp ];
                         h.pos = pos; h.d = out_d; h.T = Tchild; h.intensity = weight * diffuse_intensity;
                         h.depth = t.depth - 10; h.pixel = t.pixel;
+                        n_hp++;
                     }
                     else
                     {
-                        atomicOr( &q.counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+                        atomicOr( &p_counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
                     }
                 }
-                /* compaction of the surviving path rays into the next level's queue */
-                uint32_t cs = wave_alloc( &q.counts[ QC_CHILDREN ], hit );
+                /* the surviving path rays: the next level's queue */
+                uint32_t csl = chunk_alloc( cs + 2, &p_counts[ QC_CHILDREN ], child_cap, hit, kill_ch );
                 if( hit )
                 {
-                    if( cs < q.child_cap )
+                    if( csl < child_cap )
                     {
-                        HitRec& c = q.children[ cs ];
+                        HitRec& c = p_children[ csl ];
                         c.p = pos; c.d = out_d; c.offs = a; c.exit_nor = trans.exit_nor; c.T = Tchild;
                         c.intensity = weight * diffuse_intensity;
                         c.exit_obj = trans.exit_obj; c.enter_obj = trans.enter_obj;
                         c.depth = t.depth - 10; c.pixel = t.pixel;
+                        n_ch++;
                     }
                     else
                     {
-                        atomicOr( &q.counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+                        atomicOr( &p_counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
                     }
                 }
             }
@@ -742,30 +873,47 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
             lum.x += bg.x * bsum; lum.y += bg.y * bsum; lum.z += bg.z * bsum;
         }
 
-        if( sub == 0 ) pixel_add( accum, t.pixel, v_mld( ldc( t.Tc ), lum ) );
+        if( sub == 0 ) pixel_add( accum, sc.flags, t.pixel, v_mld( ldc( t.Tc ), lum ) );
     }
+    chunk_close( cs + 0, hard_cap, kill_hs );
+    chunk_close( cs + 1, hard_cap, kill_hp );
+    chunk_close( cs + 2, child_cap, kill_ch );
+    wave_stat_add( p_counts + QS_HARD_SHADOW, n_hs );
+    wave_stat_add( p_counts + QS_HARD_PATH, n_hp );
+    wave_stat_add( p_counts + QS_CHILDREN, n_ch );
     wave_add_counters( counters, cnt );
 }
 
-/* the shadow rays k_shade could not decide inline: full occlusion test, one lane per ray */
+/* the shadow rays k_shade could not decide inline: full occlusion test, one lane per ray, persistent waves */
 template< bool COUNT, bool LDS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_WALK_WAVES )
-void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint32_t n, uint32_t* __restrict__ p_counts,
+void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint32_t cap, uint32_t* __restrict__ p_counts,
                     unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_SCENE_VIEW
     if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     Cnt< COUNT > cnt;
     cnt.clear();
     if constexpr( LDS ) ACN_STAGE_NODES( sc )
-    if( i < n )
+    uint32_t n = p_counts[ QC_HARD_SHADOW ];
+    n = n < cap ? n : cap;
+    n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
+    for( ;; )
     {
-        HardShadow r = recs[ i ];
-        bool occ;
-        if constexpr( LDS ) occ = root_occluded( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, r.limit, &cnt );
-        else                occ = root_occluded( scene_view< PRUNE >( sc, sc.nodes ), sc.matter_root, r.pos, r.d, r.limit, &cnt );
-        if( !occ ) pixel_add( accum, r.pixel, r.contrib );
+        uint32_t first = 0;
+        uint32_t got = wave_fetch( p_counts + QC_CUR_HS, 64u, n, &first );
+        if( got == 0 ) break;
+        if( ( threadIdx.x & 63 ) < got )
+        {
+            HardShadow r = recs[ first + ( threadIdx.x & 63 ) ];
+            if( r.pixel != ACN_INVALID )
+            {
+                bool occ;
+                if constexpr( LDS ) occ = root_occluded( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, r.limit, &cnt );
+                else                occ = root_occluded( scene_view< PRUNE >( sc, sc.nodes ), sc.matter_root, r.pos, r.d, r.limit, &cnt );
+                if( !occ ) pixel_add( accum, sc.flags, r.pixel, r.contrib );
+            }
+        }
     }
     wave_add_counters( counters, cnt );
 }
@@ -773,50 +921,66 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
 /* the path rays k_shade could not finish inline: full transition hit; hits join the next level's HitRec queue */
 template< bool COUNT, bool LDS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_HPATH_WAVES )
-void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t n, HitRec* __restrict__ p_children, uint32_t child_cap,
+void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t cap, HitRec* __restrict__ p_children, uint32_t child_cap,
                   uint32_t* __restrict__ p_counts, unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
+    ACN_CHUNK_STATES
     ACN_SCENE_VIEW
     if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     Cnt< COUNT > cnt;
     cnt.clear();
     if constexpr( LDS ) ACN_STAGE_NODES( sc )
-    bool hit = false;
-    HardPath r;
-    Trans trans;
-    trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
-    double a = F3_INF;
-    if( i < n )
+    const ChunkP cs = ACN_CHUNKS_OF_WAVE;
+    chunks_init( cs );
+    uint32_t n = p_counts[ QC_HARD_PATH ];
+    n = n < cap ? n : cap;
+    n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
+    uint32_t n_ch = 0;
+    auto kill_ch = [ p_children ]( uint32_t k ) { p_children[ k ].pixel = ACN_INVALID; };
+    for( ;; )
     {
-        r = recs[ i ];
-        if constexpr( LDS ) a = root_trans_hit( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, &trans, &cnt );
-        else                a = root_trans_hit( scene_view< PRUNE >( sc, sc.nodes ), sc.matter_root, r.pos, r.d, &trans, &cnt );
-        hit = a < sc.prm.max_path_length;
-        if( !hit )
+        uint32_t first = 0;
+        uint32_t got = wave_fetch( p_counts + QC_CUR_HP, 64u, n, &first );
+        if( got == 0 ) break;
+        bool hit = false;
+        HardPath r;
+        r.pos = mk( 0, 0, 0 ); r.d = mk( 0, 0, 1 ); r.T = mk( 0, 0, 0 ); r.intensity = 0; r.depth = 0; r.pixel = ACN_INVALID;
+        Trans trans;
+        trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
+        double a = F3_INF;
+        if( ( threadIdx.x & 63 ) < got ) r = recs[ first + ( threadIdx.x & 63 ) ];
+        if( r.pixel != ACN_INVALID )
         {
-            V3 c = v_mlf( ld3( sc.prm.background_color ), r.intensity );
-            pixel_add( accum, r.pixel, v_mld( r.T, c ) );
+            if constexpr( LDS ) a = root_trans_hit( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, &trans, &cnt );
+            else                a = root_trans_hit( scene_view< PRUNE >( sc, sc.nodes ), sc.matter_root, r.pos, r.d, &trans, &cnt );
+            hit = a < sc.prm.max_path_length;
+            if( !hit )
+            {
+                V3 c = v_mlf( ld3( sc.prm.background_color ), r.intensity );
+                pixel_add( accum, sc.flags, r.pixel, v_mld( r.T, c ) );
+            }
+        }
+        uint32_t csl = chunk_alloc( cs + 0, &p_counts[ QC_CHILDREN ], child_cap, hit, kill_ch );
+        if( hit )
+        {
+            if( csl < child_cap )
+            {
+                HitRec& c = p_children[ csl ];
+                c.p = r.pos; c.d = r.d; c.offs = a; c.exit_nor = trans.exit_nor; c.T = r.T;
+                c.intensity = r.intensity;
+                c.exit_obj = trans.exit_obj; c.enter_obj = trans.enter_obj;
+                c.depth = r.depth; c.pixel = r.pixel;
+                n_ch++;
+            }
+            else
+            {
+                atomicOr( &p_counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+            }
         }
     }
-    uint32_t cs = wave_alloc( &p_counts[ QC_CHILDREN ], hit );
-    if( hit )
-    {
-        if( cs < child_cap )
-        {
-            HitRec& c = p_children[ cs ];
-            c.p = r.pos; c.d = r.d; c.offs = a; c.exit_nor = trans.exit_nor; c.T = r.T;
-            c.intensity = r.intensity;
-            c.exit_obj = trans.exit_obj; c.enter_obj = trans.enter_obj;
-            c.depth = r.depth; c.pixel = r.pixel;
-        }
-        else
-        {
-            atomicOr( &p_counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
-        }
-    }
+    chunk_close( cs + 0, child_cap, kill_ch );
+    wave_stat_add( p_counts + QS_CHILDREN, n_ch );
     wave_add_counters( counters, cnt );
 }
-
 
 #endif /* ACN_PIPELINE_H */

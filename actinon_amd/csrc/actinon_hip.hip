@@ -16,12 +16,6 @@
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* error plumbing */
-/* The lanes' streams must land on different hardware queues to overlap; ROCm maps streams onto GPU_MAX_HW_QUEUES
- * (default 4) queues and with 4 of them two of four lane streams were seen to share one (105 vs 87 ms on the 1080p
- * frame).  Raised to 8 unless the user set it; effective when this library is loaded before the HIP runtime
- * initialises (the C command line tool).  Python hosts set it before importing torch (actinon_amd/__init__.py, bench.py). */
-static const int g_hw_queues_default = setenv( "GPU_MAX_HW_QUEUES", "8", 0 );
-
 static thread_local std::string g_last_error;
 static int fail( int code, const std::string& msg ) { g_last_error = msg; return code; }
 extern "C" const char* acn_last_error( void ) { return g_last_error.c_str(); }
@@ -73,6 +67,50 @@ struct LaneWorker
     }
 };
 
+/* Tunables, read from the environment ONCE per acn_scene_upload (never from the render path: getenv there would race a
+ * host that changes its environment, and would let a value change between the concurrent lanes of one call) */
+struct Tunables
+{
+    size_t   workspace_mb = 16384;     /* ACN_WORKSPACE_MB: upper bound of the queue workspace of one handle (all its lanes) */
+    size_t   chunk = 0;                /* ACN_CHUNK: sample positions per pipeline run, 0 = derived from the queue capacity */
+    int      lanes = 2;                /* ACN_LANES: concurrent pipeline runs of a large call */
+    unsigned grid = 0;                 /* ACN_GRID: workgroups of the persistent kernels, 0 = 4 per compute unit */
+    unsigned shade_grid = 0;           /* ACN_SHADE_GRID: workgroups of k_shade, 0 = 4 per compute unit */
+    uint32_t stack_cap = 512;          /* ACN_STACK_CAP: private ray slots per k_walk wave */
+    uint32_t stack_use = 0;            /* ACN_TEST_STACK_USE: slots the first walk launch of a level uses (tests of the mop-up launch) */
+    bool     count_work = false;       /* ACN_COUNT_WORK */
+    bool     stage_timing = false;     /* ACN_STAGE_TIMING */
+    void read()
+    {
+        if( const char* e = getenv( "ACN_WORKSPACE_MB" ) ) workspace_mb = ( size_t )atoll( e );
+        if( const char* e = getenv( "ACN_CHUNK" ) ) chunk = ( size_t )atoll( e );
+        if( const char* e = getenv( "ACN_LANES" ) ) lanes = atoi( e );
+        if( const char* e = getenv( "ACN_GRID" ) ) grid = ( unsigned )atoi( e );
+        if( const char* e = getenv( "ACN_SHADE_GRID" ) ) shade_grid = ( unsigned )atoi( e );
+        if( const char* e = getenv( "ACN_STACK_CAP" ) ) stack_cap = ( uint32_t )atoll( e );
+        if( const char* e = getenv( "ACN_TEST_STACK_USE" ) ) stack_use = ( uint32_t )atoll( e );
+        count_work = getenv( "ACN_COUNT_WORK" ) != nullptr;
+        stage_timing = getenv( "ACN_STAGE_TIMING" ) != nullptr;
+        if( lanes < 1 ) lanes = 1;
+        if( lanes > 16 ) lanes = 16;
+        if( stack_cap < 256 ) stack_cap = 256;
+        if( stack_use == 0 || stack_use > stack_cap ) stack_use = stack_cap;
+    }
+};
+
+/* the queue workspace of one pipeline run */
+struct Workspace
+{
+    DTask*      tasks = nullptr;
+    uint32_t*   idx[ ACN_NCLASS ] = { nullptr, nullptr, nullptr, nullptr };
+    HitRec*     children = nullptr;
+    HardShadow* hard_shadow = nullptr;
+    HardPath*   hard_path = nullptr;
+    RayTask*    rays[ 2 ] = { nullptr, nullptr };
+    RayTask*    stacks = nullptr;   size_t stack_waves = 0;
+    uint32_t    cap = 0;            /* records per queue */
+};
+
 struct acn_scene_handle
 {
     int device = 0;
@@ -87,11 +125,13 @@ struct acn_scene_handle
     int cur_stage = 0;
     bool stage_timing = false;                 /* ACN_OPT_STAGE_TIMING of the current call */
     int max_csg_depth = 0;
+    Tunables tun;
+    unsigned grid = 1024, shade_grid = 1024;   /* workgroups of the persistent kernels / of k_shade */
+    int n_levels = 1;                          /* path levels of the scene's trace_depth */
     /* workspace of the wavefront pipeline */
-    Queues q{};
-    RayTask* rays[ 2 ] = { nullptr, nullptr };  /* ping-pong ray queues of the specular walk */
-    RayTask* chase_buf = nullptr;  uint32_t chase_max = 0;   /* block-private queues of k_trace_chase */
-    uint32_t* h_counts = nullptr;              /* pinned */
+    Workspace ws;
+    uint32_t* d_counts = nullptr;              /* ACN_MAX_PATH_LEVELS + 1 counter blocks of QC_N words */
+    uint32_t* h_counts = nullptr;              /* pinned copy */
     unsigned long long* d_accum = nullptr;  size_t accum_cap = 0;
     unsigned long long* d_counters = nullptr;
     std::vector< StageEvents > events;  size_t events_used = 0;
@@ -101,7 +141,8 @@ struct acn_scene_handle
     bool leaf_lights = true;                   /* every light element is a plane / sphere */
     bool count_work = false;                   /* ACN_OPT_COUNT_WORK of the current call */
     uint64_t launches[ 4 ] = { 0, 0, 0, 0 };   /* walk, shade, finalize, hard-ray kernels */
-    uint64_t hard_rays = 0, walk_passes = 0, walk_rays = 0, shade_hit_recs = 0;
+    uint64_t hard_rays = 0, walk_steps = 0, walk_rays = 0, shade_hit_recs = 0, host_syncs = 0;
+    uint32_t flags_seen = 0;                   /* ACN_FLAG_* bits of the last call */
     size_t good_chunk = 0;
     uint64_t chunks = 0, retries = 0, levels = 0;
     uint64_t peak_tasks = 0, peak_children = 0;
@@ -116,6 +157,7 @@ struct acn_scene_handle
     std::string lane_error;
     bool used_lanes = false;                   /* the last render call ran through the lanes: statistics are their sums */
 };
+#define ACN_LEVEL_BLOCKS ( ACN_MAX_PATH_LEVELS + 1 )
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* kernels */
@@ -382,6 +424,16 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     acn_scene_handle* h = new acn_scene_handle();
     h->device = device;
     h->max_csg_depth = max_csg;
+    h->tun.read();
+    {
+        int cus = 0;
+        if( hipDeviceGetAttribute( &cus, hipDeviceAttributeMultiprocessorCount, device ) != hipSuccess || cus <= 0 ) cus = 256;
+        h->grid = h->tun.grid ? h->tun.grid : ( unsigned )cus * 4u;               /* 4 workgroups of 256 lanes per CU: occupancy 4 */
+        h->shade_grid = h->tun.shade_grid ? h->tun.shade_grid : ( unsigned )cus * 4u;
+        /* path levels: level L shades hits at depth trace_depth - 10 L and spawns the next one while that is > 10 (scene.c:584) */
+        uint64_t td = scene->params.trace_depth;
+        h->n_levels = scene->params.path_samples && td > 10 ? 1 + ( int )( ( td - 10 + 9 ) / 10 ) : 1;
+    }
     auto bail = [ & ]( int code ) { acn_scene_free( h ); return code; };
 #define HIP_TRY_H( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) \
     return bail( fail( ACN_ERR_DEVICE, std::string( #expr ) + ": " + hipGetErrorString( e_ ) ) ); } while( 0 )
@@ -627,8 +679,8 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     if( scene->n_textures ) HIP_TRY_H( hipMemcpy( h->d_textures, scene->textures, sizeof( acn_texture ) * scene->n_textures, hipMemcpyHostToDevice ) );
     HIP_TRY_H( hipMalloc( &h->d_counters, sizeof( unsigned long long ) * CNT_N ) );
     HIP_TRY_H( hipMemset( h->d_counters, 0, sizeof( unsigned long long ) * CNT_N ) );
-    HIP_TRY_H( hipMalloc( &h->q.counts, sizeof( uint32_t ) * QC_N ) );
-    HIP_TRY_H( hipHostMalloc( &h->h_counts, sizeof( uint32_t ) * QC_N ) );
+    HIP_TRY_H( hipMalloc( &h->d_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
+    HIP_TRY_H( hipHostMalloc( &h->h_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
     HIP_TRY_H( hipMemcpy( h->d_nodes, nodes.data(), sizeof( GNode ) * scene->n_nodes, hipMemcpyHostToDevice ) );
     HIP_TRY_H( hipMemcpy( h->d_mats, mats.data(), sizeof( GMat ) * scene->n_nodes, hipMemcpyHostToDevice ) );
     HIP_TRY_H( hipMemcpy( h->d_elems, elems2.data(), sizeof( int32_t ) * elems2.size(), hipMemcpyHostToDevice ) );
@@ -663,9 +715,9 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
         if( const char* e = getenv( "ACN_LDS_STACK" ) ) stack = atoi( e ) != 0;
         h->lds_stack_bytes = stack ? ACN_LDS_STACK_BYTES : 0;
     }
-    h->dev.flags = h->q.counts + QC_FLAGS;
+    h->dev.flags = h->d_counts + QC_FLAGS;
     h->dev.lds_stack = h->lds_stack_bytes ? 0u : ACN_NO_LDS_STACK;   /* the kernels that own a stack area set the offset */
-    HIP_TRY_H( hipMemset( h->q.counts, 0, sizeof( uint32_t ) * QC_N ) );
+    HIP_TRY_H( hipMemset( h->d_counts, 0, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
     /* camera basis on the device so that it shares the device's arithmetic */
     {
         M3* d_rot = nullptr; double* d_uf = nullptr;
@@ -684,17 +736,15 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
 
 static void free_workspace( acn_scene_handle* h )
 {
-    if( h->q.tasks ) hipFree( h->q.tasks );
-    for( int k = 0; k < ACN_NCLASS; k++ ) if( h->q.idx[ k ] ) hipFree( h->q.idx[ k ] );
-    if( h->q.children ) hipFree( h->q.children );
-    if( h->q.hard_shadow ) hipFree( h->q.hard_shadow );
-    if( h->q.hard_path ) hipFree( h->q.hard_path );
-    for( int k = 0; k < 2; k++ ) { if( h->rays[ k ] ) hipFree( h->rays[ k ] ); h->rays[ k ] = nullptr; }
-    if( h->chase_buf ) hipFree( h->chase_buf );
-    h->chase_buf = nullptr; h->chase_max = 0;
-    h->q.hard_shadow = nullptr; h->q.hard_path = nullptr; h->q.hard_cap = 0;
-    h->q.tasks = nullptr; h->q.children = nullptr; h->q.task_cap = h->q.child_cap = 0;
-    for( int k = 0; k < ACN_NCLASS; k++ ) h->q.idx[ k ] = nullptr;
+    Workspace& w = h->ws;
+    if( w.tasks ) hipFree( w.tasks );
+    for( int k = 0; k < ACN_NCLASS; k++ ) if( w.idx[ k ] ) hipFree( w.idx[ k ] );
+    if( w.children ) hipFree( w.children );
+    if( w.hard_shadow ) hipFree( w.hard_shadow );
+    if( w.hard_path ) hipFree( w.hard_path );
+    for( int k = 0; k < 2; k++ ) if( w.rays[ k ] ) hipFree( w.rays[ k ] );
+    if( w.stacks ) hipFree( w.stacks );
+    w = Workspace();
 }
 
 extern "C" void acn_scene_free( acn_scene_handle* h )
@@ -705,7 +755,7 @@ extern "C" void acn_scene_free( acn_scene_handle* h )
     h->lanes.clear();
     if( h->worker ) { h->worker->stop(); delete h->worker; h->worker = nullptr; }
     free_workspace( h );
-    if( h->q.counts ) hipFree( h->q.counts );
+    if( h->d_counts ) hipFree( h->d_counts );
     if( h->h_counts ) hipHostFree( h->h_counts );
     if( h->d_accum ) hipFree( h->d_accum );
     if( h->d_lane_pos ) hipFree( h->d_lane_pos );
@@ -725,32 +775,52 @@ extern "C" void acn_scene_free( acn_scene_handle* h )
     delete h;
 }
 
-/* queue capacities for a call over n positions: enough for every path sample of the largest chunk to hit, bounded
- * by ACN_WORKSPACE_MB (default 65536) */
+/* bytes of queue workspace per record of capacity */
+static size_t bytes_per_record()
+{
+    return sizeof( HitRec ) + sizeof( DTask ) + ACN_NCLASS * sizeof( uint32_t ) + sizeof( HardShadow ) + sizeof( HardPath ) + 2 * sizeof( RayTask );
+}
+
+/* Queue capacities.  Only one chunk of positions is in flight per pipeline run, so the queues are sized for a chunk,
+ * not for the call: enough for every path sample of ACN_CHUNK_TARGET positions (or of the whole call if it is smaller)
+ * to survive into the next level, bounded by the handle's budget (ACN_WORKSPACE_MB, default 16 GiB, shared by its
+ * lanes).  If the device cannot give that much, the request is halved until it fits: the chunk size follows the
+ * capacity (launch_render), so a small workspace costs more chunks, not correctness. */
+#define ACN_CHUNK_TARGET ( ( size_t )1 << 18 )
 static int ensure_workspace( acn_scene_handle* h, size_t n )
 {
-    size_t budget_mb = 65536;
-    if( const char* e = getenv( "ACN_WORKSPACE_MB" ) ) budget_mb = ( size_t )atoll( e );
-    budget_mb /= h->budget_div;
-    size_t per_rec = sizeof( HitRec ) + sizeof( DTask ) + ACN_NCLASS * sizeof( uint32_t ) + sizeof( HardShadow ) + sizeof( HardPath ) + 2 * sizeof( RayTask );
-    size_t max_recs = budget_mb * 1024 * 1024 / per_rec;
+    Workspace& w = h->ws;
+    size_t budget = h->tun.workspace_mb * 1024 * 1024 / h->budget_div;
+    size_t stack_waves = ( size_t )h->grid * 4;
+    size_t stack_bytes = stack_waves * h->tun.stack_cap * sizeof( RayTask );
+    size_t max_recs = budget > stack_bytes ? ( budget - stack_bytes ) / bytes_per_record() : 0;
     size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
-    size_t want = n * ( s + 2 ) + 65536;
+    size_t positions = n < ACN_CHUNK_TARGET ? n : ACN_CHUNK_TARGET;
+    size_t want = positions * ( s + 2 ) + 65536;
     if( want > max_recs ) want = max_recs;
     if( want < 65536 ) want = 65536;
     if( want > 0xFFFFFF00ull ) want = 0xFFFFFF00ull;
-    if( h->q.child_cap >= want ) return ACN_OK;
+    if( w.cap >= want && w.stack_waves >= stack_waves ) return ACN_OK;
     free_workspace( h );
-    HIP_TRY( hipMalloc( &h->q.children, sizeof( HitRec ) * want ) );
-    HIP_TRY( hipMalloc( &h->q.tasks, sizeof( DTask ) * want ) );
-    for( int k = 0; k < ACN_NCLASS; k++ ) HIP_TRY( hipMalloc( &h->q.idx[ k ], sizeof( uint32_t ) * want ) );
-    HIP_TRY( hipMalloc( &h->q.hard_shadow, sizeof( HardShadow ) * want ) );
-    HIP_TRY( hipMalloc( &h->q.hard_path, sizeof( HardPath ) * want ) );
-    for( int k = 0; k < 2; k++ ) HIP_TRY( hipMalloc( &h->rays[ k ], sizeof( RayTask ) * want ) );
-    h->q.ray_cap = ( uint32_t )want;
-    h->q.child_cap = ( uint32_t )want;
-    h->q.task_cap = ( uint32_t )want;
-    h->q.hard_cap = ( uint32_t )want;
+    for( ;; )
+    {
+        hipError_t e = hipSuccess;
+        auto grab = [ & ]( void** p, size_t bytes ) { if( e == hipSuccess ) e = hipMalloc( p, bytes ); };
+        grab( ( void** )&w.children, sizeof( HitRec ) * want );
+        grab( ( void** )&w.tasks, sizeof( DTask ) * want );
+        for( int k = 0; k < ACN_NCLASS; k++ ) grab( ( void** )&w.idx[ k ], sizeof( uint32_t ) * want );
+        grab( ( void** )&w.hard_shadow, sizeof( HardShadow ) * want );
+        grab( ( void** )&w.hard_path, sizeof( HardPath ) * want );
+        for( int k = 0; k < 2; k++ ) grab( ( void** )&w.rays[ k ], sizeof( RayTask ) * want );
+        grab( ( void** )&w.stacks, stack_bytes );
+        if( e == hipSuccess ) break;
+        ( void )hipGetLastError();
+        free_workspace( h );
+        if( want <= 65536 ) return fail( ACN_ERR_DEVICE, std::string( "queue workspace: " ) + hipGetErrorString( e ) );
+        want = want / 2 < 65536 ? 65536 : want / 2;
+    }
+    w.cap = ( uint32_t )want;
+    w.stack_waves = stack_waves;
     return ACN_OK;
 }
 
@@ -780,13 +850,6 @@ static int stage_end( acn_scene_handle* h, hipStream_t stream )
     return ACN_OK;
 }
 
-static int read_counts( acn_scene_handle* h, hipStream_t stream )
-{
-    HIP_TRY( hipMemcpyAsync( h->h_counts, h->q.counts, sizeof( uint32_t ) * QC_N, hipMemcpyDeviceToHost, stream ) );
-    HIP_TRY( hipStreamSynchronize( stream ) );
-    return ACN_OK;
-}
-
 static SceneArgs scene_args( const acn_scene_handle* h )
 {
     SceneArgs s;
@@ -799,157 +862,86 @@ static KernelFlags kernel_flags( const acn_scene_handle* h )
     f.count = h->count_work; f.leaf_lights = h->leaf_lights; f.lds_nodes = h->lds_bytes != 0; f.prune = h->prune;
     return f;
 }
-static WalkQueueArgs walk_queue_args( const acn_scene_handle* h, int out )
+/* the workspace as the kernels of path level `level` see it */
+static LevelQ level_queues( const acn_scene_handle* h, int level )
 {
-    WalkQueueArgs q;
-    q.tasks = h->q.tasks; for( int k = 0; k < 4; k++ ) q.idx[ k ] = h->q.idx[ k ];
-    q.counts = h->q.counts; q.task_cap = h->q.task_cap; q.rays_out = h->rays[ out ]; q.ray_cap = h->q.ray_cap;
+    const Workspace& w = h->ws;
+    LevelQ q;
+    q.tasks = w.tasks; for( int k = 0; k < ACN_NCLASS; k++ ) q.idx[ k ] = w.idx[ k ];
+    q.task_cap = q.child_cap = q.hard_cap = q.ray_cap = w.cap;
+    q.children = w.children; q.hard_shadow = w.hard_shadow; q.hard_path = w.hard_path;
+    q.rays_a = w.rays[ 0 ]; q.rays_b = w.rays[ 1 ];
+    q.stacks = w.stacks; q.stack_cap = h->tun.stack_cap; q.stack_use = h->tun.stack_use;
+    q.counts = h->d_counts + ( size_t )level * QC_N;
+    q.prev_children = h->d_counts + ( size_t )( level > 0 ? level - 1 : 0 ) * QC_N + QC_CHILDREN;
+    q.grid = h->grid; q.shade_grid = h->shade_grid;
     return q;
 }
 static size_t machine_lds_bytes( const acn_scene_handle* h ) { return h->lds_bytes + h->lds_stack_bytes; }
 
-template< int LPT >
-static int launch_shade( acn_scene_handle* h, int cls, uint32_t n_tasks, hipStream_t stream )
-{
-    if( n_tasks == 0 ) return ACN_OK;
-    constexpr int G = 64 / LPT;
-    size_t waves = ( ( size_t )n_tasks + G - 1 ) / G;
-    size_t blocks = ( waves + 3 ) / 4;
-    if( blocks > 256 * 32 ) blocks = 256 * 32;
-    int st = stage_begin( h, 1, stream );
-    if( st != ACN_OK ) return st;
-    auto fn = LPT == 64 ? acn_launch_shade64 : LPT == 16 ? acn_launch_shade16 : LPT == 4 ? acn_launch_shade4 : acn_launch_shade1;
-    fn( kernel_flags( h ), ( unsigned )blocks, stream, scene_args( h ), ( const DTask* )h->q.tasks, ( const uint32_t* )h->q.idx[ cls ], n_tasks,
-        h->q.children, h->q.child_cap, h->q.hard_shadow, h->q.hard_path, h->q.hard_cap, h->q.counts, h->d_accum, h->d_counters );
-    HIP_TRY( hipGetLastError() );
-    return stage_end( h, stream );
-}
+#define ACN_LAUNCH( h, stage, stream, call ) do { int st_ = stage_begin( h, stage, stream ); if( st_ != ACN_OK ) return st_; call; \
+    HIP_TRY( hipGetLastError() ); if( ( st_ = stage_end( h, stream ) ) != ACN_OK ) return st_; } while( 0 )
 
-static int check_flags( acn_scene_handle* h, int* overflow )
-{
-    if( h->h_counts[ QC_FLAGS ] & ACN_FLAG_STACK_OVERFLOW ) return fail( ACN_ERR_UNSUPPORTED, "device CSG / compound stack overflow" );
-    if( h->h_counts[ QC_FLAGS ] ) *overflow = 1;
-    return ACN_OK;
-}
-
-/* the specular walk of one level: passes of k_trace_rays until no ray is left. `n_in` rays wait in rays[ *cur ]. */
-static int walk_passes( acn_scene_handle* h, uint32_t n_in, int* cur, hipStream_t stream, int* overflow )
-{
-    int st;
-    for( int pass = 0; n_in > 0; pass++ )
-    {
-        if( pass > 4096 ) return fail( ACN_ERR_DEVICE, "specular walk does not terminate" );
-        int in = *cur, out = 1 - in;
-        HIP_TRY( hipMemsetAsync( h->q.counts + QC_RAYS, 0, 2 * sizeof( uint32_t ), stream ) );   /* QC_RAYS, QC_CHASED */
-        /* a small generation: one launch follows it and its descendants to the end (k_trace_chase) */
-        const char* chase_env = getenv( "ACN_CHASE_MAX" );
-        const uint32_t chase_limit = chase_env ? ( uint32_t )atoll( chase_env ) : 32768u;
-        bool chase = !h->count_work && n_in <= chase_limit;
-        if( chase && h->chase_max < chase_limit )
-        {
-            if( h->chase_buf ) hipFree( h->chase_buf );
-            h->chase_buf = nullptr; h->chase_max = 0;
-            HIP_TRY( hipMalloc( &h->chase_buf, acn_chase_buffer_bytes( chase_limit ) ) );
-            h->chase_max = chase_limit;
-        }
-        if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
-        if( chase )
-        {
-            acn_launch_trace_chase( kernel_flags( h ), n_in, machine_lds_bytes( h ), stream, scene_args( h ), walk_queue_args( h, out ),
-                                    ( const RayTask* )h->rays[ in ], h->chase_buf, h->d_accum, h->d_counters );
-        }
-        else
-        {
-        h->walk_rays += n_in;
-        acn_launch_trace( false, kernel_flags( h ), n_in, machine_lds_bytes( h ), stream, scene_args( h ), walk_queue_args( h, out ),
-                          ( const RayTask* )h->rays[ in ], nullptr, 0, 0u, h->d_accum, h->d_counters );
-        }
-        HIP_TRY( hipGetLastError() );
-        if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
-        if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
-        if( ( st = check_flags( h, overflow ) ) != ACN_OK || *overflow ) return st;
-        h->walk_passes++;
-        h->walk_rays += h->h_counts[ QC_CHASED ];
-        n_in = h->h_counts[ QC_RAYS ];
-        *cur = out;
-    }
-    return ACN_OK;
-}
-
-/* One chunk of positions [ base, base + cnt ): per path level  walk passes -> k_shade -> hard-ray kernels. */
+/* One chunk of positions [ base, base + cnt ).  The whole chain -- per path level: ( k_shade_hits -> ) k_walk -> its
+ * mop-up launch -> k_shade x 4 size classes -> k_hard_shadow -> k_hard_path -- is enqueued blind: every kernel takes
+ * its input count from the counter block of its level on the device, and a level that turns out to be empty costs a few
+ * launches of waves that exit at once.  The host synchronises ONCE, at the end, to read the counter blocks: overflow
+ * flags (the chunk is then redone smaller) and statistics. */
 static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t first_pixel, uint32_t base, uint32_t cnt,
                          hipStream_t stream, int* overflow )
 {
     *overflow = 0;
-    int st;
-    int cur = 0;
-    HIP_TRY( hipMemsetAsync( h->q.counts, 0, sizeof( uint32_t ) * QC_N, stream ) );
-    /* level 0, pass 0: the camera rays */
-    if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
-    h->walk_rays += cnt;
-    acn_launch_trace( true, kernel_flags( h ), cnt, machine_lds_bytes( h ), stream, scene_args( h ), walk_queue_args( h, cur ),
-                      nullptr, d_pos_xy, first_pixel, base, h->d_accum, h->d_counters );
-    HIP_TRY( hipGetLastError() );
-    if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
-    if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
-    if( ( st = check_flags( h, overflow ) ) != ACN_OK || *overflow ) return st;
-    if( ( st = walk_passes( h, h->h_counts[ QC_RAYS ], &cur, stream, overflow ) ) != ACN_OK || *overflow ) return st;
-
-    for( int level = 0; level < ACN_MAX_PATH_LEVELS + 1; level++ )
+    const int levels = h->n_levels;
+    const KernelFlags f = kernel_flags( h );
+    const SceneArgs s = scene_args( h );
+    const size_t lds = machine_lds_bytes( h );
+    HIP_TRY( hipMemsetAsync( h->d_counts, 0, sizeof( uint32_t ) * QC_N * levels, stream ) );
+    for( int level = 0; level < levels; level++ )
     {
-        /* h_counts holds the counts after the last walk pass of this level */
-        uint32_t n_cls[ ACN_NCLASS ];
-        uint32_t total = 0;
-        for( int k = 0; k < ACN_NCLASS; k++ ) { n_cls[ k ] = h->h_counts[ QC_CLASS0 + k ]; total += n_cls[ k ]; }
-        if( h->h_counts[ QC_TASKS ] > h->peak_tasks ) h->peak_tasks = h->h_counts[ QC_TASKS ];
-        if( total == 0 ) break;
-        h->levels++;
-        HIP_TRY( hipMemsetAsync( h->q.counts + QC_CHILDREN, 0, sizeof( uint32_t ), stream ) );
-        HIP_TRY( hipMemsetAsync( h->q.counts + QC_HARD_SHADOW, 0, 2 * sizeof( uint32_t ), stream ) );
-        if( ( st = launch_shade< 64 >( h, 0, n_cls[ 0 ], stream ) ) != ACN_OK ) return st;
-        if( ( st = launch_shade< 16 >( h, 1, n_cls[ 1 ], stream ) ) != ACN_OK ) return st;
-        if( ( st = launch_shade< 4 >( h, 2, n_cls[ 2 ], stream ) ) != ACN_OK ) return st;
-        if( ( st = launch_shade< 1 >( h, 3, n_cls[ 3 ], stream ) ) != ACN_OK ) return st;
-        if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
-        if( ( st = check_flags( h, overflow ) ) != ACN_OK || *overflow ) return st;
-        /* the rays k_shade deferred: full traversal, one lane per ray */
+        const LevelQ q = level_queues( h, level );
+        if( level == 0 )
         {
-            uint32_t n_hs = h->h_counts[ QC_HARD_SHADOW ], n_hp = h->h_counts[ QC_HARD_PATH ];
-            h->hard_rays += ( uint64_t )n_hs + n_hp;
-            if( n_hs )
-            {
-                if( ( st = stage_begin( h, 3, stream ) ) != ACN_OK ) return st;
-                acn_launch_hard_shadow( kernel_flags( h ), n_hs, machine_lds_bytes( h ), stream, scene_args( h ),
-                                        ( const HardShadow* )h->q.hard_shadow, h->q.counts, h->d_accum, h->d_counters );
-                HIP_TRY( hipGetLastError() );
-                if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
-            }
-            if( n_hp )
-            {
-                if( ( st = stage_begin( h, 3, stream ) ) != ACN_OK ) return st;
-                acn_launch_hard_path( kernel_flags( h ), n_hp, machine_lds_bytes( h ), stream, scene_args( h ),
-                                      ( const HardPath* )h->q.hard_path, h->q.children, h->q.child_cap, h->q.counts, h->d_accum, h->d_counters );
-                HIP_TRY( hipGetLastError() );
-                if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
-                if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
-                if( ( st = check_flags( h, overflow ) ) != ACN_OK || *overflow ) return st;
-            }
+            ACN_LAUNCH( h, 0, stream, acn_launch_walk( f, false, q, lds, stream, s, d_pos_xy, first_pixel, base, cnt, h->d_accum, h->d_counters ) );
         }
-        uint32_t n_children = h->h_counts[ QC_CHILDREN ];
-        if( n_children > h->peak_children ) h->peak_children = n_children;
-        if( n_children == 0 ) break;
-        /* next level: the task queues are consumed; the path-sample hits are shaded, then their specular rays walked */
-        HIP_TRY( hipMemsetAsync( h->q.counts, 0, sizeof( uint32_t ) * QC_CHILDREN, stream ) );
-        HIP_TRY( hipMemsetAsync( h->q.counts + QC_RAYS, 0, sizeof( uint32_t ), stream ) );
-        if( ( st = stage_begin( h, 0, stream ) ) != ACN_OK ) return st;
-        h->shade_hit_recs += n_children;
-        acn_launch_shade_hits( h->count_work, n_children, stream, scene_args( h ), walk_queue_args( h, cur ),
-                               ( const HitRec* )h->q.children, h->d_accum, h->d_counters );
-        HIP_TRY( hipGetLastError() );
-        if( ( st = stage_end( h, stream ) ) != ACN_OK ) return st;
-        if( ( st = read_counts( h, stream ) ) != ACN_OK ) return st;
-        if( ( st = check_flags( h, overflow ) ) != ACN_OK || *overflow ) return st;
-        if( ( st = walk_passes( h, h->h_counts[ QC_RAYS ], &cur, stream, overflow ) ) != ACN_OK || *overflow ) return st;
+        else
+        {
+            /* the path-sample hits of the level before are shaded, then their specular rays walked */
+            ACN_LAUNCH( h, 0, stream, acn_launch_shade_hits( f.count, q, stream, s, h->d_accum, h->d_counters ) );
+            ACN_LAUNCH( h, 0, stream, acn_launch_walk( f, false, q, lds, stream, s, nullptr, 0, 0, 0, h->d_accum, h->d_counters ) );
+        }
+        ACN_LAUNCH( h, 0, stream, acn_launch_walk( f, true, q, lds, stream, s, nullptr, 0, 0, 0, h->d_accum, h->d_counters ) );
+        ACN_LAUNCH( h, 1, stream, acn_launch_shade64( f, q, stream, s, h->d_accum, h->d_counters ) );
+        ACN_LAUNCH( h, 1, stream, acn_launch_shade16( f, q, stream, s, h->d_accum, h->d_counters ) );
+        ACN_LAUNCH( h, 1, stream, acn_launch_shade4( f, q, stream, s, h->d_accum, h->d_counters ) );
+        ACN_LAUNCH( h, 1, stream, acn_launch_shade1( f, q, stream, s, h->d_accum, h->d_counters ) );
+        ACN_LAUNCH( h, 3, stream, acn_launch_hard_shadow( f, q, lds, stream, s, h->d_accum, h->d_counters ) );
+        if( level + 1 < levels )   /* the last level casts no path rays (depth <= 10) */
+            ACN_LAUNCH( h, 3, stream, acn_launch_hard_path( f, q, lds, stream, s, h->d_accum, h->d_counters ) );
+    }
+    HIP_TRY( hipMemcpyAsync( h->h_counts, h->d_counts, sizeof( uint32_t ) * QC_N * levels, hipMemcpyDeviceToHost, stream ) );
+    HIP_TRY( hipStreamSynchronize( stream ) );
+    h->host_syncs++;
+    uint32_t flags = 0;
+    for( int level = 0; level < levels; level++ )
+    {
+        const uint32_t* c = h->h_counts + ( size_t )level * QC_N;
+        flags |= c[ QC_FLAGS ];
+        if( c[ QC_RAYS_OVF2 ] ) flags |= ACN_FLAG_CHILD_OVERFLOW;   /* rays left over by the mop-up launch */
+    }
+    h->flags_seen |= flags & ACN_FLAG_CLAMPED;
+    if( flags & ACN_FLAG_STACK_OVERFLOW ) return fail( ACN_ERR_UNSUPPORTED, "device CSG / compound stack overflow (or a walk that did not end)" );
+    if( flags & ( ACN_FLAG_TASK_OVERFLOW | ACN_FLAG_CHILD_OVERFLOW ) ) { *overflow = 1; return ACN_OK; }
+    for( int level = 0; level < levels; level++ )
+    {
+        const uint32_t* c = h->h_counts + ( size_t )level * QC_N;
+        if( c[ QC_TASKS ] == 0 && c[ QS_WALK_RAYS ] == 0 ) break;
+        h->levels++;
+        h->walk_rays += c[ QS_WALK_RAYS ];
+        h->walk_steps += c[ QS_WALK_STEPS ];
+        h->hard_rays += ( uint64_t )c[ QS_HARD_SHADOW ] + c[ QS_HARD_PATH ];
+        h->shade_hit_recs += c[ QS_CHILDREN ];
+        if( c[ QC_TASKS ] > h->peak_tasks ) h->peak_tasks = c[ QC_TASKS ];
+        if( c[ QC_CHILDREN ] > h->peak_children ) h->peak_children = c[ QC_CHILDREN ];
     }
     return ACN_OK;
 }
@@ -961,8 +953,8 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     if( n == 0 ) return ACN_OK;
     if( n > 0xFFFFFF00ull ) return fail( ACN_ERR_ARG, "too many positions in one call" );
     int linear = ( opts && ( opts->flags & ACN_OPT_LINEAR_OUT ) ) ? 1 : 0;
-    h->count_work = ( opts && ( opts->flags & ACN_OPT_COUNT_WORK ) ) || getenv( "ACN_COUNT_WORK" ) != nullptr;
-    h->stage_timing = ( opts && ( opts->flags & ACN_OPT_STAGE_TIMING ) ) || getenv( "ACN_STAGE_TIMING" ) != nullptr;
+    h->count_work = ( opts && ( opts->flags & ACN_OPT_COUNT_WORK ) ) || h->tun.count_work;
+    h->stage_timing = ( opts && ( opts->flags & ACN_OPT_STAGE_TIMING ) ) || h->tun.stage_timing;
     int st = ensure_workspace( h, n );
     if( st != ACN_OK ) return st;
     if( h->accum_cap < n )
@@ -974,19 +966,18 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     }
     h->events_used = 0;
     h->launches[ 0 ] = h->launches[ 1 ] = h->launches[ 2 ] = h->launches[ 3 ] = 0;
-    h->hard_rays = 0; h->walk_passes = 0; h->walk_rays = 0; h->shade_hit_recs = 0;
+    h->hard_rays = 0; h->walk_steps = 0; h->walk_rays = 0; h->shade_hit_recs = 0; h->host_syncs = 0; h->flags_seen = 0;
     h->chunks = h->retries = h->levels = 0;
     h->peak_tasks = h->peak_children = 0;
     HIP_TRY( hipMemsetAsync( h->d_counters, 0, sizeof( unsigned long long ) * CNT_N, stream ) );
     HIP_TRY( hipEventRecord( h->ev0, stream ) );
     HIP_TRY( hipMemsetAsync( h->d_accum, 0, sizeof( unsigned long long ) * 3 * n, stream ) );
 
-    /* chunk so that every path sample of a chunk may survive into the next level's queue */
-    /* optimistic start (a quarter of the path samples survive); an overflow halves the chunk and the size that worked
-     * is remembered for the next call on this handle */
+    /* positions per pipeline run: optimistic start (a quarter of the path samples survive into the next level's
+     * queue); an overflow halves the chunk and the size that worked is remembered for the next call on this handle */
     size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
-    size_t chunk = h->good_chunk ? h->good_chunk : h->q.child_cap / ( s / 4 + 2 );
-    if( const char* e = getenv( "ACN_CHUNK" ) ) chunk = ( size_t )atoll( e );
+    size_t chunk = h->good_chunk ? h->good_chunk : h->ws.cap / ( s / 4 + 2 );
+    if( h->tun.chunk ) chunk = h->tun.chunk;
     if( chunk < 256 ) chunk = 256;
     size_t base = 0;
     while( base < n )
@@ -1084,30 +1075,28 @@ static int make_lane( acn_scene_handle* parent, int lanes, acn_scene_handle** ou
     l->max_csg_depth = parent->max_csg_depth;
     l->lds_bytes = parent->lds_bytes; l->lds_stack_bytes = parent->lds_stack_bytes;
     l->prune = parent->prune; l->leaf_lights = parent->leaf_lights;
+    l->tun = parent->tun; l->grid = parent->grid; l->shade_grid = parent->shade_grid; l->n_levels = parent->n_levels;
 #define HIP_TRY_L( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) { acn_scene_free( l ); return fail( ACN_ERR_DEVICE, hipGetErrorString( e_ ) ); } } while( 0 )
     HIP_TRY_L( hipStreamCreateWithFlags( &l->stream, hipStreamNonBlocking ) );
     HIP_TRY_L( hipEventCreate( &l->ev0 ) );
     HIP_TRY_L( hipEventCreate( &l->ev1 ) );
     HIP_TRY_L( hipMalloc( &l->d_counters, sizeof( unsigned long long ) * CNT_N ) );
     HIP_TRY_L( hipMemset( l->d_counters, 0, sizeof( unsigned long long ) * CNT_N ) );
-    HIP_TRY_L( hipMalloc( &l->q.counts, sizeof( uint32_t ) * QC_N ) );
-    HIP_TRY_L( hipMemset( l->q.counts, 0, sizeof( uint32_t ) * QC_N ) );
-    HIP_TRY_L( hipHostMalloc( &l->h_counts, sizeof( uint32_t ) * QC_N ) );
+    HIP_TRY_L( hipMalloc( &l->d_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
+    HIP_TRY_L( hipMemset( l->d_counts, 0, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
+    HIP_TRY_L( hipHostMalloc( &l->h_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
 #undef HIP_TRY_L
-    l->dev.flags = l->q.counts + QC_FLAGS;
+    l->dev.flags = l->d_counts + QC_FLAGS;
     l->worker = new LaneWorker();
     l->worker->start();
     *out = l;
     return ACN_OK;
 }
 
-/* number of lanes for a call of n positions: ACN_LANES (default 4), one lane below 32 tiles per lane */
-static int lanes_for( size_t n )
+/* number of lanes for a call of n positions: the handle's ACN_LANES, one lane below 32 tiles per lane */
+static int lanes_for( const acn_scene_handle* h, size_t n )
 {
-    int lanes = 4;
-    if( const char* e = getenv( "ACN_LANES" ) ) lanes = atoi( e );
-    if( lanes < 1 ) lanes = 1;
-    if( lanes > 16 ) lanes = 16;
+    int lanes = h->tun.lanes;
     while( lanes > 1 && n < ( size_t )lanes * 32 * ACN_LANE_TILE ) lanes--;
     return lanes;
 }
@@ -1170,7 +1159,7 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
     /* statistics of the call: sums / maxima over the lanes */
     h->events_used = 0;
     h->launches[ 0 ] = h->launches[ 1 ] = h->launches[ 2 ] = h->launches[ 3 ] = 0;
-    h->hard_rays = h->walk_passes = h->walk_rays = h->shade_hit_recs = 0;
+    h->hard_rays = h->walk_steps = h->walk_rays = h->shade_hit_recs = h->host_syncs = 0; h->flags_seen = 0;
     h->chunks = h->retries = h->levels = 0;
     h->peak_tasks = h->peak_children = 0;
     for( int k = 0; k < lanes; k++ )
@@ -1178,7 +1167,8 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
         const acn_scene_handle* l = h->lanes[ k ];
         if( lane_count( n, lanes, k ) == 0 ) continue;
         for( int i = 0; i < 4; i++ ) h->launches[ i ] += l->launches[ i ];
-        h->hard_rays += l->hard_rays; h->walk_passes += l->walk_passes; h->walk_rays += l->walk_rays; h->shade_hit_recs += l->shade_hit_recs;
+        h->hard_rays += l->hard_rays; h->walk_steps += l->walk_steps; h->walk_rays += l->walk_rays; h->shade_hit_recs += l->shade_hit_recs;
+        h->host_syncs += l->host_syncs; h->flags_seen |= l->flags_seen;
         h->chunks += l->chunks; h->retries += l->retries;
         if( l->levels > h->levels ) h->levels = l->levels;
         h->peak_tasks += l->peak_tasks; h->peak_children += l->peak_children;
@@ -1192,7 +1182,7 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
 static int render_dispatch( acn_scene_handle* h, const double* d_pos_xy, size_t first, size_t n, double* d_out_rgb,
                             const acn_render_opts* opts, hipStream_t stream )
 {
-    int lanes = lanes_for( n );
+    int lanes = lanes_for( h, n );
     h->used_lanes = false;
     if( lanes <= 1 ) return launch_render( h, d_pos_xy, first, n, d_out_rgb, opts, stream );
     return render_lanes( h, lanes, d_pos_xy, first, n, d_out_rgb, opts, stream );
@@ -1271,16 +1261,16 @@ extern "C" int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms )
 
 extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
 {
-    if( !h || !out || n < 0 || n > 18 || !h->timed ) return fail( ACN_ERR_ARG, "no timed launch" );
+    if( !h || !out || n < 0 || n > 21 || !h->timed ) return fail( ACN_ERR_ARG, "no timed launch" );
     HIP_TRY( hipSetDevice( h->device ) );
     HIP_TRY( hipEventSynchronize( h->ev1 ) );
     double ms[ 4 ] = { 0, 0, 0, 0 };
-    size_t queue_cap = h->q.child_cap;
+    size_t queue_cap = h->ws.cap;
     std::vector< const acn_scene_handle* > src{ h };
     if( h->used_lanes ) { src.assign( h->lanes.begin(), h->lanes.end() ); queue_cap = 0; }   /* stage times: summed over the concurrent lanes */
     for( const acn_scene_handle* l : src )
     {
-        if( h->used_lanes ) queue_cap += l->q.child_cap;
+        if( h->used_lanes ) queue_cap += l->ws.cap;
         for( size_t i = 0; i < l->events_used; i++ )
         {
             float t = 0;
@@ -1290,11 +1280,12 @@ extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
     }
     float total = 0;
     HIP_TRY( hipEventElapsedTime( &total, h->ev0, h->ev1 ) );
-    double v[ 18 ] = { ms[ 0 ], ms[ 1 ], ms[ 2 ], total, ( double )h->launches[ 0 ], ( double )h->launches[ 1 ], ( double )h->launches[ 2 ],
+    double v[ 21 ] = { ms[ 0 ], ms[ 1 ], ms[ 2 ], total, ( double )h->launches[ 0 ], ( double )h->launches[ 1 ], ( double )h->launches[ 2 ],
                        ( double )h->chunks, ( double )h->retries, ( double )h->levels, ( double )h->peak_tasks, ( double )h->peak_children,
                        ( double )queue_cap, ms[ 3 ], ( double )h->launches[ 3 ], ( double )h->hard_rays,
-                       ( double )h->walk_rays, ( double )h->shade_hit_recs };
-    for( int k = 0; k < n && k < 18; k++ ) out[ k ] = v[ k ];
+                       ( double )h->walk_rays, ( double )h->shade_hit_recs, ( double )h->host_syncs, ( double )h->walk_steps,
+                       ( double )h->flags_seen };
+    for( int k = 0; k < n && k < 21; k++ ) out[ k ] = v[ k ];
     return ACN_OK;
 }
 

@@ -2,13 +2,12 @@
 #include <hip/hip_runtime.h>
 #include "acn_launch.h"
 
-#define ACN_LHS_( C, L, P ) hipLaunchKernelGGL( ( k_hard_shadow< C, L, P > ), dim3( ( n + 255 ) / 256 ), dim3( 256 ), lds_bytes, stream, \
-    ACN_SCENE_ARGS_OF( s ), recs, n, counts, accum, counters )
-void acn_launch_hard_shadow( KernelFlags f, uint32_t n, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
-                             const HardShadow* recs, uint32_t* counts, unsigned long long* accum, unsigned long long* counters )
+#define ACN_LHS_( C, L, P ) hipLaunchKernelGGL( ( k_hard_shadow< C, L, P > ), dim3( q.grid ), dim3( 256 ), lds_bytes, stream, \
+    ACN_SCENE_ARGS_OF( s ), ( const HardShadow* )q.hard_shadow, q.hard_cap, q.counts, accum, counters )
+void acn_launch_hard_shadow( KernelFlags f, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
+                             unsigned long long* accum, unsigned long long* counters )
 {
     if( f.count )      { if( f.lds_nodes ) ACN_LHS_( true, true, false );  else ACN_LHS_( true, false, false ); }
     else if( f.prune ) { if( f.lds_nodes ) ACN_LHS_( false, true, true );  else ACN_LHS_( false, false, true ); }
     else               { if( f.lds_nodes ) ACN_LHS_( false, true, false ); else ACN_LHS_( false, false, false ); }
 }
-

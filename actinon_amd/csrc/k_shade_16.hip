@@ -1,4 +1,4 @@
 /* k_shade< 16, ... >: see acn_launch.h */
 #include <hip/hip_runtime.h>
 #include "acn_launch.h"
-ACN_DEFINE_LAUNCH_SHADE( acn_launch_shade16, 16 )
+ACN_DEFINE_LAUNCH_SHADE( acn_launch_shade16, 16, 1 )

@@ -1,0 +1,11 @@
+/* k_walk< false, false, * > (node array read from global memory / L2): see acn_launch.h */
+#include <hip/hip_runtime.h>
+#include "acn_launch.h"
+
+void acn_launch_walk_glb( KernelFlags f, bool mop, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
+                          const double* pos_xy, size_t first_pixel, uint32_t base, uint32_t n_cam,
+                          unsigned long long* accum, unsigned long long* counters )
+{
+    if( f.prune ) ACN_LW_( false, false, true );
+    else          ACN_LW_( false, false, false );
+}

@@ -187,8 +187,8 @@ int acn_render_positions( acn_scene_handle* h, const double* pos_xy, size_t n, d
 
 /* Same on device-resident buffers (d_pos_xy, d_out_rgb are device pointers on the handle's device).
  * Work is enqueued on opts->stream (NULL = the handle's own stream, then the call also waits for completion).
- * The call reads the level queues' fill counts back between path levels, so it synchronises that stream a few
- * times per call; on return the last kernels may still be in flight on a caller-provided stream. */
+ * The call synchronises that stream once per chunk of positions (queue-overflow check); on return the last kernels may
+ * still be in flight on a caller-provided stream. */
 int acn_render_positions_dev( acn_scene_handle* h, const void* d_pos_xy, size_t n, void* d_out_rgb,
                               const acn_render_opts* opts );
 
@@ -213,7 +213,9 @@ int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms );
  * out[0] walk kernels ms, [1] shade kernels ms, [2] finalize ms, [3] total ms, [4..6] launches per stage, [7] chunks,
  * [8] overflow retries, [9] path levels run, [10] peak shading tasks, [11] peak child hits, [12] queue capacity,
  * [13] hard-ray kernels ms, [14] their launches, [15] hard rays, [16] rays traced by the specular walk (camera rays
- * included), [17] path-sample hits shaded (levels >= 1). n <= 18. */
+ * included), [17] path-sample hits shaded (levels >= 1), [18] host synchronisations inside the pipeline (one per chunk),
+ * [19] 64-ray steps of the walk kernel's waves ([16] / ( 64 * [19] ) is its lane occupancy), [20] ACN_FLAG_* bits seen
+ * (8: a pixel contribution exceeded the fixed-point clamp of 16384). n <= 21. */
 int acn_last_stage_ms( acn_scene_handle* h, double* out, int n );
 
 /* Work counters of the last render call (rays cast, node visits ...), see DESIGN.md. n <= 16. */

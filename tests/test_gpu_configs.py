@@ -49,7 +49,8 @@ def strided_positions(flat, count):
     """`count` pixel centres spread over the whole raster: every (W*H // count)-th pixel in raster order, the stride
     made odd so that the columns drift from row to row."""
     w, h = int(flat.params.image_width), int(flat.params.image_height)
-    stride = (w * h // count) | 1
+    stride = w * h // count
+    stride -= 1 - stride % 2
     idx = np.arange(0, w * h, stride)[:count]
     return A.main_pass_positions(w, h)[idx]
 
@@ -102,8 +103,8 @@ def test_queue_overflow_retry_is_bit_identical(oracle, monkeypatch):
     assert st["retries"] > 0 and st["chunks"] > 1, st
     assert np.array_equal(forced, ref)
     # ... and through the concurrent lanes, each with its share of the small workspace
-    monkeypatch.setenv("ACN_LANES", "4")
-    monkeypatch.setenv("ACN_WORKSPACE_MB", "192")
+    monkeypatch.setenv("ACN_LANES", "2")
+    monkeypatch.setenv("ACN_WORKSPACE_MB", "96")
     h = A.Handle(flat)
     forced4 = h.render_positions(pos, linear=True)
     st4 = h.last_stages()
@@ -118,7 +119,7 @@ def test_queue_overflow_retry_is_bit_identical(oracle, monkeypatch):
 def test_cancel_flag_inside_the_library(monkeypatch):
     """acn_render_opts.cancel is the SIGINT flag of src/scene.c:893,978: set before the call nothing is rendered; set
     while the call is running the library stops between two chunks and returns ACN_ERR_CANCELLED."""
-    sc = A.Scene.build("diamond", image_width=256, image_height=256, path_samples=128, direct_samples=50)
+    sc = A.Scene.build("diamond", image_width=256, image_height=256, path_samples=256, direct_samples=50)
     flat = sc.flatten()
     pos = S.positions(flat)
     monkeypatch.setenv("ACN_CHUNK", "512")                # many chunks: many polls

@@ -198,24 +198,32 @@ def test_many_spheres_with_gpu_auto_envelopes(oracle):
     assert np.abs(gpu - cpu).max() <= TOL
 
 
-def test_lanes_and_generation_chase_do_not_change_a_pixel(oracle, monkeypatch):
-    """Concurrent lanes (ACN_LANES) and the fused tail of the specular walk (ACN_CHASE_MAX) reorganise the work, not the
-    arithmetic: the frame is bit-identical with and without them, and equals the oracle on a sample of its pixels."""
+def test_lanes_grid_and_mop_up_do_not_change_a_pixel(oracle, monkeypatch):
+    """Concurrent lanes (ACN_LANES), the size of the persistent grid (ACN_GRID) and the mop-up launch of the specular walk
+    (forced by letting the first walk launch use one slot of each wave's ray stack, ACN_TEST_STACK_USE) reorganise the
+    work, not the arithmetic: the frame is bit-identical in every arrangement and equals the oracle on a sample of pixels."""
     sc = A.Scene.build("wine_glass", image_width=320, image_height=180, path_samples=16, direct_samples=50)
     flat = sc.flatten()
     pos = S.positions(flat)
     assert len(pos) >= 4 * 32 * 256          # enough tiles for four lanes
     frames = {}
-    for label, lanes, chase in (("plain", "1", "0"), ("lanes", "4", "0"), ("chase", "1", "32768"), ("both", "4", "32768")):
-        monkeypatch.setenv("ACN_LANES", lanes)
-        monkeypatch.setenv("ACN_CHASE_MAX", chase)
+    for label, env in (("plain", dict(ACN_LANES="1")), ("lanes", dict(ACN_LANES="4")),
+                       ("small_grid", dict(ACN_LANES="1", ACN_GRID="7", ACN_SHADE_GRID="5")),
+                       ("mop_up", dict(ACN_LANES="1", ACN_TEST_STACK_USE="1")),
+                       ("all", dict(ACN_LANES="3", ACN_GRID="96", ACN_TEST_STACK_USE="3"))):
+        for k in ("ACN_LANES", "ACN_GRID", "ACN_SHADE_GRID", "ACN_TEST_STACK_USE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)                 # read by acn_scene_upload
         h = A.Handle(flat)
         frames[label] = (h.render_positions(pos, linear=True), h.last_stages())
         h.close()
-    for label in ("lanes", "chase", "both"):
+    for label in ("lanes", "small_grid", "mop_up", "all"):
         assert np.array_equal(frames[label][0], frames["plain"][0]), label
-        assert frames[label][1]["walk_rays"] == frames["plain"][1]["walk_rays"]
-    assert frames["chase"][1]["walk_launches"] < frames["plain"][1]["walk_launches"]
+        assert frames[label][1]["walk_rays"] == frames["plain"][1]["walk_rays"], label
+        assert frames[label][1]["hard_rays"] == frames["plain"][1]["hard_rays"], label
+    # one host synchronisation per chunk and lane, however many specular generations there are
+    assert frames["plain"][1]["host_syncs"] == frames["plain"][1]["chunks"]
     sample = np.arange(0, len(pos), 37)
     cpu = oracle.render_positions(flat, pos[sample], linear=True)
-    assert np.abs(frames["both"][0][sample] - cpu).max() <= TOL
+    assert np.abs(frames["all"][0][sample] - cpu).max() <= TOL
