@@ -34,6 +34,7 @@ struct LevelQ
     const uint32_t* prev_children;
     unsigned grid;                                          /* workgroups of the persistent kernels */
     unsigned shade_grid;                                    /* workgroups of k_shade */
+    uint32_t fetch_walk, fetch_hard;                        /* input items a wave reserves per cursor atomic */
 };
 
 /* one launch of the specular walk.  n_cam > 0: the fresh input are the camera rays of positions [ base, base + n_cam );
@@ -62,15 +63,15 @@ void acn_launch_hard_path( KernelFlags f, const LevelQ& q, size_t lds_bytes, hip
     if( n_cam ) \
         hipLaunchKernelGGL( ( k_walk< C, L, R > ), dim3( q.grid ), dim3( 256 ), lds_bytes, stream, ACN_SCENE_ARGS_OF( s ), ACN_TASKQ_ARGS_OF( q ), \
             ( const RayTask* )nullptr, ( const uint32_t* )nullptr, 0u, pos_xy, first_pixel, base, n_cam, \
-            ( uint32_t )QC_CUR_WALK, ( uint32_t )QC_RAYS_OVF, q.rays_b, q.ray_cap, q.stacks, q.stack_cap, q.stack_use, accum, counters ); \
+            ( uint32_t )QC_CUR_WALK, ( uint32_t )QC_RAYS_OVF, q.rays_b, q.ray_cap, q.stacks, q.stack_cap, q.stack_use, q.fetch_walk, accum, counters ); \
     else if( !mop ) \
         hipLaunchKernelGGL( ( k_walk< C, L, R > ), dim3( q.grid ), dim3( 256 ), lds_bytes, stream, ACN_SCENE_ARGS_OF( s ), ACN_TASKQ_ARGS_OF( q ), \
             ( const RayTask* )q.rays_a, ( const uint32_t* )( q.counts + QC_RAYS ), q.ray_cap, ( const double* )nullptr, ( size_t )0, 0u, 0u, \
-            ( uint32_t )QC_CUR_WALK, ( uint32_t )QC_RAYS_OVF, q.rays_b, q.ray_cap, q.stacks, q.stack_cap, q.stack_use, accum, counters ); \
+            ( uint32_t )QC_CUR_WALK, ( uint32_t )QC_RAYS_OVF, q.rays_b, q.ray_cap, q.stacks, q.stack_cap, q.stack_use, q.fetch_walk, accum, counters ); \
     else \
         hipLaunchKernelGGL( ( k_walk< C, L, R > ), dim3( q.grid ), dim3( 256 ), lds_bytes, stream, ACN_SCENE_ARGS_OF( s ), ACN_TASKQ_ARGS_OF( q ), \
             ( const RayTask* )q.rays_b, ( const uint32_t* )( q.counts + QC_RAYS_OVF ), q.ray_cap, ( const double* )nullptr, ( size_t )0, 0u, 0u, \
-            ( uint32_t )QC_CUR_MOP, ( uint32_t )QC_RAYS_OVF2, ( RayTask* )nullptr, 0u, q.stacks, q.stack_cap, q.stack_cap, accum, counters ); \
+            ( uint32_t )QC_CUR_MOP, ( uint32_t )QC_RAYS_OVF2, ( RayTask* )nullptr, 0u, q.stacks, q.stack_cap, q.stack_cap, q.fetch_walk, accum, counters ); \
     } while( 0 )
 
 /* body of acn_launch_shade<LPT>: shared by the four k_shade translation units */

@@ -259,6 +259,25 @@ DEV uint32_t wave_fetch( uint32_t* cursor, uint32_t want, uint32_t n, uint32_t* 
     return n - b < want ? n - b : want;
 }
 
+/* the same in batches: the wave owns the range [ cur, end ) of the input and refills it with ONE atomic per `batch`
+ * items (all three are the same in every lane) */
+struct FetchRange { uint32_t cur, end; bool more; };
+DEV uint32_t range_take( FetchRange& r, uint32_t* cursor, uint32_t batch, uint32_t n, uint32_t want, uint32_t* first )
+{
+    if( r.cur == r.end && r.more )
+    {
+        uint32_t b = 0;
+        uint32_t got = wave_fetch( cursor, batch, n, &b );
+        r.cur = b; r.end = b + got;
+        if( b + batch >= n ) r.more = false;
+    }
+    uint32_t have = r.end - r.cur;
+    uint32_t take = have < want ? have : want;
+    *first = r.cur;
+    r.cur += take;
+    return take;
+}
+
 /* ---- where shade_hit puts what it produces ---- */
 
 /* the queues of diffuse shading tasks: tasks[] + one index list per size class */
@@ -533,7 +552,7 @@ __global__ __launch_bounds__( 256, ACN_TRACE_WAVES )
 void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ rays_in, const uint32_t* __restrict__ n_in_ptr, uint32_t in_cap,
              const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n_cam,
              uint32_t cur_slot, uint32_t ovf_slot, RayTask* __restrict__ ovf_rays, uint32_t ovf_cap,
-             RayTask* __restrict__ stacks, uint32_t stack_stride, uint32_t stack_cap,
+             RayTask* __restrict__ stacks, uint32_t stack_stride, uint32_t stack_cap, uint32_t fetch_batch,
              unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_CHUNK_STATES
@@ -554,7 +573,8 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
     st.stack = stacks + ( size_t )wave * stack_stride; st.cap = stack_cap; st.top = 0;
     st.ovf.rays = ovf_rays; st.ovf.counter = p_counts + ovf_slot; st.ovf.cap = ovf_cap; st.ovf.flags = p_counts + QC_FLAGS; st.ovf.cs = cs + 5;
     uint32_t* cursor = p_counts + cur_slot;
-    bool more = n_in > 0;
+    FetchRange fr;
+    fr.cur = fr.end = 0; fr.more = n_in > 0;
     uint32_t traced = 0, steps = 0;
     bool finished = false;
     for( uint32_t step = 0; step < ACN_WALK_MAX_STEPS; step++ )
@@ -562,11 +582,7 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
         /* the step's 64 rays: the top of the private stack, topped up with fresh input */
         uint32_t n_pop = st.top < 64u ? st.top : 64u;
         uint32_t n_fresh = 0, fb = 0;
-        if( more && n_pop < 64u )
-        {
-            n_fresh = wave_fetch( cursor, 64u - n_pop, n_in, &fb );
-            if( fb + ( 64u - n_pop ) >= n_in ) more = false;
-        }
+        if( n_pop < 64u ) n_fresh = range_take( fr, cursor, fetch_batch, n_in, 64u - n_pop, &fb );
         if( n_pop + n_fresh == 0 ) { finished = true; break; }
         st.top -= n_pop;
         const RayTask* src = nullptr;
@@ -635,7 +651,7 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
  * scene.c:610); persistent waves fetch 64 records at a time.  n_ptr: the previous level's QC_CHILDREN. */
 template< bool COUNT >
 __global__ __launch_bounds__( 256, ACN_WALK_WAVES )
-void k_shade_hits( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const HitRec* __restrict__ recs, const uint32_t* __restrict__ n_ptr, uint32_t rec_cap,
+void k_shade_hits( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const HitRec* __restrict__ recs, const uint32_t* __restrict__ n_ptr, uint32_t rec_cap, uint32_t fetch_batch,
                    RayTask* __restrict__ rays_out, uint32_t ray_cap,
                    unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
@@ -651,10 +667,12 @@ void k_shade_hits( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const HitRec* __restrict_
     n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
     RayQ rq;
     rq.rays = rays_out; rq.counter = p_counts + QC_RAYS; rq.cap = ray_cap; rq.flags = p_counts + QC_FLAGS; rq.cs = cs + 5;
+    FetchRange fr;
+    fr.cur = fr.end = 0; fr.more = n > 0;
     for( ;; )
     {
         uint32_t first = 0;
-        uint32_t got = wave_fetch( p_counts + QC_CUR_HITS, 64u, n, &first );
+        uint32_t got = range_take( fr, p_counts + QC_CUR_HITS, fetch_batch, n, 64u, &first );
         if( got == 0 ) break;
         uint32_t i = first + ( threadIdx.x & 63 );
         bool live = ( threadIdx.x & 63 ) < got;
@@ -887,7 +905,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
 /* the shadow rays k_shade could not decide inline: full occlusion test, one lane per ray, persistent waves */
 template< bool COUNT, bool LDS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_WALK_WAVES )
-void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint32_t cap, uint32_t* __restrict__ p_counts,
+void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint32_t cap, uint32_t fetch_batch, uint32_t* __restrict__ p_counts,
                     unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_SCENE_VIEW
@@ -898,10 +916,12 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
     uint32_t n = p_counts[ QC_HARD_SHADOW ];
     n = n < cap ? n : cap;
     n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
+    FetchRange fr;
+    fr.cur = fr.end = 0; fr.more = n > 0;
     for( ;; )
     {
         uint32_t first = 0;
-        uint32_t got = wave_fetch( p_counts + QC_CUR_HS, 64u, n, &first );
+        uint32_t got = range_take( fr, p_counts + QC_CUR_HS, fetch_batch, n, 64u, &first );
         if( got == 0 ) break;
         if( ( threadIdx.x & 63 ) < got )
         {
@@ -921,7 +941,7 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
 /* the path rays k_shade could not finish inline: full transition hit; hits join the next level's HitRec queue */
 template< bool COUNT, bool LDS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_HPATH_WAVES )
-void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t cap, HitRec* __restrict__ p_children, uint32_t child_cap,
+void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t cap, uint32_t fetch_batch, HitRec* __restrict__ p_children, uint32_t child_cap,
                   uint32_t* __restrict__ p_counts, unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_CHUNK_STATES
@@ -937,10 +957,12 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
     n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
     uint32_t n_ch = 0;
     auto kill_ch = [ p_children ]( uint32_t k ) { p_children[ k ].pixel = ACN_INVALID; };
+    FetchRange fr;
+    fr.cur = fr.end = 0; fr.more = n > 0;
     for( ;; )
     {
         uint32_t first = 0;
-        uint32_t got = wave_fetch( p_counts + QC_CUR_HP, 64u, n, &first );
+        uint32_t got = range_take( fr, p_counts + QC_CUR_HP, fetch_batch, n, 64u, &first );
         if( got == 0 ) break;
         bool hit = false;
         HardPath r;

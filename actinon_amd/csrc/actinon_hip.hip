@@ -77,6 +77,8 @@ struct Tunables
     unsigned grid = 0;                 /* ACN_GRID: workgroups of the persistent kernels, 0 = 4 per compute unit */
     unsigned shade_grid = 0;           /* ACN_SHADE_GRID: workgroups of k_shade, 0 = 4 per compute unit */
     uint32_t stack_cap = 512;          /* ACN_STACK_CAP: private ray slots per k_walk wave */
+    uint32_t fetch_walk = 256;         /* ACN_FETCH_WALK: fresh rays a k_walk wave reserves per cursor atomic */
+    uint32_t fetch_hard = 256;         /* ACN_FETCH_HARD: records a wave of the hard-ray kernels / k_shade_hits reserves per atomic */
     uint32_t stack_use = 0;            /* ACN_TEST_STACK_USE: slots the first walk launch of a level uses (tests of the mop-up launch) */
     bool     count_work = false;       /* ACN_COUNT_WORK */
     bool     stage_timing = false;     /* ACN_STAGE_TIMING */
@@ -89,6 +91,10 @@ struct Tunables
         if( const char* e = getenv( "ACN_SHADE_GRID" ) ) shade_grid = ( unsigned )atoi( e );
         if( const char* e = getenv( "ACN_STACK_CAP" ) ) stack_cap = ( uint32_t )atoll( e );
         if( const char* e = getenv( "ACN_TEST_STACK_USE" ) ) stack_use = ( uint32_t )atoll( e );
+        if( const char* e = getenv( "ACN_FETCH_WALK" ) ) fetch_walk = ( uint32_t )atoll( e );
+        if( const char* e = getenv( "ACN_FETCH_HARD" ) ) fetch_hard = ( uint32_t )atoll( e );
+        if( fetch_walk < 64 ) fetch_walk = 64;
+        if( fetch_hard < 64 ) fetch_hard = 64;
         count_work = getenv( "ACN_COUNT_WORK" ) != nullptr;
         stage_timing = getenv( "ACN_STAGE_TIMING" ) != nullptr;
         if( lanes < 1 ) lanes = 1;
@@ -143,7 +149,7 @@ struct acn_scene_handle
     uint64_t launches[ 4 ] = { 0, 0, 0, 0 };   /* walk, shade, finalize, hard-ray kernels */
     uint64_t hard_rays = 0, walk_steps = 0, walk_rays = 0, shade_hit_recs = 0, host_syncs = 0;
     uint32_t flags_seen = 0;                   /* ACN_FLAG_* bits of the last call */
-    size_t good_chunk = 0;
+    double recs_per_pos = 0;                   /* learned: the fullest queue's records per sample position (chunk sizing) */
     uint64_t chunks = 0, retries = 0, levels = 0;
     uint64_t peak_tasks = 0, peak_children = 0;
     /* concurrent lanes (render_lanes): clones of this handle that share the resident scene and own a stream and a
@@ -782,8 +788,8 @@ static size_t bytes_per_record()
 }
 
 /* Queue capacities.  Only one chunk of positions is in flight per pipeline run, so the queues are sized for a chunk,
- * not for the call: enough for every path sample of ACN_CHUNK_TARGET positions (or of the whole call if it is smaller)
- * to survive into the next level, bounded by the handle's budget (ACN_WORKSPACE_MB, default 16 GiB, shared by its
+ * not for the call: room for the path-sample hits of ACN_CHUNK_TARGET positions (or of the whole call if it is smaller)
+ * over two path levels, bounded by the handle's budget (ACN_WORKSPACE_MB, default 16 GiB, shared by its
  * lanes).  If the device cannot give that much, the request is halved until it fits: the chunk size follows the
  * capacity (launch_render), so a small workspace costs more chunks, not correctness. */
 #define ACN_CHUNK_TARGET ( ( size_t )1 << 18 )
@@ -796,7 +802,8 @@ static int ensure_workspace( acn_scene_handle* h, size_t n )
     size_t max_recs = budget > stack_bytes ? ( budget - stack_bytes ) / bytes_per_record() : 0;
     size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
     size_t positions = n < ACN_CHUNK_TARGET ? n : ACN_CHUNK_TARGET;
-    size_t want = positions * ( s + 2 ) + 65536;
+    /* the second path level multiplies the hits of the first by path_samples * intensity again (scene.c:593-610) */
+    size_t want = positions * ( s + 2 ) * ( s > 16 ? s / 16 : 1 ) + 65536;
     if( want > max_recs ) want = max_recs;
     if( want < 65536 ) want = 65536;
     if( want > 0xFFFFFF00ull ) want = 0xFFFFFF00ull;
@@ -875,6 +882,7 @@ static LevelQ level_queues( const acn_scene_handle* h, int level )
     q.counts = h->d_counts + ( size_t )level * QC_N;
     q.prev_children = h->d_counts + ( size_t )( level > 0 ? level - 1 : 0 ) * QC_N + QC_CHILDREN;
     q.grid = h->grid; q.shade_grid = h->shade_grid;
+    q.fetch_walk = h->tun.fetch_walk; q.fetch_hard = h->tun.fetch_hard;
     return q;
 }
 static size_t machine_lds_bytes( const acn_scene_handle* h ) { return h->lds_bytes + h->lds_stack_bytes; }
@@ -888,9 +896,10 @@ static size_t machine_lds_bytes( const acn_scene_handle* h ) { return h->lds_byt
  * launches of waves that exit at once.  The host synchronises ONCE, at the end, to read the counter blocks: overflow
  * flags (the chunk is then redone smaller) and statistics. */
 static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t first_pixel, uint32_t base, uint32_t cnt,
-                         hipStream_t stream, int* overflow )
+                         hipStream_t stream, int* overflow, uint32_t* fullest )
 {
     *overflow = 0;
+    *fullest = 0;
     const int levels = h->n_levels;
     const KernelFlags f = kernel_flags( h );
     const SceneArgs s = scene_args( h );
@@ -942,6 +951,9 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
         h->shade_hit_recs += c[ QS_CHILDREN ];
         if( c[ QC_TASKS ] > h->peak_tasks ) h->peak_tasks = c[ QC_TASKS ];
         if( c[ QC_CHILDREN ] > h->peak_children ) h->peak_children = c[ QC_CHILDREN ];
+        /* the fullest queue of the chunk: what the next chunk's size is derived from */
+        const int q_slots[] = { QC_TASKS, QC_CLASS0, QC_CLASS0 + 1, QC_CLASS0 + 2, QC_CLASS0 + 3, QC_CHILDREN, QC_HARD_SHADOW, QC_HARD_PATH, QC_RAYS, QC_RAYS_OVF };
+        for( int k : q_slots ) if( c[ k ] > *fullest ) *fullest = c[ k ];
     }
     return ACN_OK;
 }
@@ -973,31 +985,49 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     HIP_TRY( hipEventRecord( h->ev0, stream ) );
     HIP_TRY( hipMemsetAsync( h->d_accum, 0, sizeof( unsigned long long ) * 3 * n, stream ) );
 
-    /* positions per pipeline run: optimistic start (a quarter of the path samples survive into the next level's
-     * queue); an overflow halves the chunk and the size that worked is remembered for the next call on this handle */
+    /* Positions per pipeline run.  How many records a position produces differs by orders of magnitude between scenes
+     * (wine_glass: 30 deferred shadow rays per pixel; a closed room at path_samples 1024: 260 000 second-level hits), so
+     * the size is learned: a cautious first chunk, then 70 % of what the fullest queue of the last chunk says fits; an
+     * overflow halves the chunk.  The estimate stays with the handle for its next call. */
     size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
-    size_t chunk = h->good_chunk ? h->good_chunk : h->ws.cap / ( s / 4 + 2 );
+    const double cap = ( double )h->ws.cap;
+    size_t chunk;
+    if( h->recs_per_pos > 0 ) chunk = ( size_t )( 0.7 * cap / h->recs_per_pos );
+    else chunk = ( size_t )( cap / ( ( double )( s + 2 ) * ( s > 16 ? ( double )s / 16.0 : 1.0 ) ) );
     if( h->tun.chunk ) chunk = h->tun.chunk;
-    if( chunk < 256 ) chunk = 256;
+    if( chunk < 64 ) chunk = 64;
     size_t base = 0;
     while( base < n )
     {
         if( opts && opts->cancel && *opts->cancel ) return fail( ACN_ERR_CANCELLED, "cancelled" );
         uint32_t cnt = ( uint32_t )( ( n - base < chunk ) ? n - base : chunk );
         int overflow = 0;
-        st = render_chunk( h, d_pos_xy, first, ( uint32_t )base, cnt, stream, &overflow );
+        uint32_t fullest = 0;
+        st = render_chunk( h, d_pos_xy, first, ( uint32_t )base, cnt, stream, &overflow, &fullest );
         if( st != ACN_OK ) return st;
         if( overflow )
         {
-            if( cnt <= 64 ) return fail( ACN_ERR_DEVICE, "work queues overflow even for 64 positions: raise ACN_WORKSPACE_MB" );
+            if( cnt <= 1 ) return fail( ACN_ERR_DEVICE, "work queues overflow for a single position: raise ACN_WORKSPACE_MB" );
             h->retries++;
             chunk = cnt / 2;
-            h->good_chunk = chunk;
+            h->recs_per_pos = cap / ( double )chunk;
             HIP_TRY( hipMemsetAsync( h->d_accum + 3 * base, 0, sizeof( unsigned long long ) * 3 * cnt, stream ) );
             continue;
         }
         h->chunks++;
         base += cnt;
+        if( !h->tun.chunk )
+        {
+            /* dead slots of the queue reservations ( <= 64 per wave and kernel ) do not scale with the chunk */
+            double slack = 64.0 * 4 * h->grid * 6;
+            double per_pos = ( ( double )fullest > slack ? ( double )fullest - slack : ( double )fullest * 0.25 ) / ( double )cnt;
+            if( per_pos < 1e-3 ) per_pos = 1e-3;
+            h->recs_per_pos = per_pos;
+            double next = 0.7 * ( cap - slack > 0 ? cap - slack : cap ) / per_pos;
+            if( next > 2.0e9 ) next = 2.0e9;
+            chunk = ( size_t )next;
+            if( chunk < 64 ) chunk = 64;
+        }
     }
     if( ( st = stage_begin( h, 2, stream ) ) != ACN_OK ) return st;
     hipLaunchKernelGGL( k_finalize, dim3( ( unsigned )( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, stream,

@@ -3,7 +3,7 @@
 #include "acn_launch.h"
 
 #define ACN_LHP_( C, L, P ) hipLaunchKernelGGL( ( k_hard_path< C, L, P > ), dim3( q.grid ), dim3( 256 ), lds_bytes, stream, \
-    ACN_SCENE_ARGS_OF( s ), ( const HardPath* )q.hard_path, q.hard_cap, q.children, q.child_cap, q.counts, accum, counters )
+    ACN_SCENE_ARGS_OF( s ), ( const HardPath* )q.hard_path, q.hard_cap, q.fetch_hard, q.children, q.child_cap, q.counts, accum, counters )
 void acn_launch_hard_path( KernelFlags f, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
                            unsigned long long* accum, unsigned long long* counters )
 {

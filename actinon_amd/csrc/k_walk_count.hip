@@ -11,7 +11,7 @@ void acn_launch_walk_count( KernelFlags f, bool mop, const LevelQ& q, size_t lds
 }
 
 #define ACN_LSH_( C ) hipLaunchKernelGGL( ( k_shade_hits< C > ), dim3( q.grid ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS_OF( s ), ACN_TASKQ_ARGS_OF( q ), \
-    ( const HitRec* )q.children, q.prev_children, q.child_cap, q.rays_a, q.ray_cap, accum, counters )
+    ( const HitRec* )q.children, q.prev_children, q.child_cap, q.fetch_hard, q.rays_a, q.ray_cap, accum, counters )
 void acn_launch_shade_hits( bool count, const LevelQ& q, hipStream_t stream, const SceneArgs& s,
                             unsigned long long* accum, unsigned long long* counters )
 {
