@@ -27,19 +27,21 @@ struct LevelQ
     DTask* tasks; uint32_t* idx[ ACN_NCLASS ]; uint32_t task_cap;
     HitRec* children; uint32_t child_cap;
     HardShadow* hard_shadow; HardPath* hard_path; uint32_t hard_cap;
-    RayTask* rays_a; RayTask* rays_b; uint32_t ray_cap;     /* a: k_shade_hits -> k_walk; b: k_walk -> mop-up launch */
+    RayTask* rays[ 2 ]; uint32_t ray_cap;                   /* generation g of the walk waits in rays[ g & 1 ] */
     RayTask* stacks; uint32_t stack_cap;                    /* private ray stacks of the k_walk waves: grid * 4 of them */
-    uint32_t stack_use;                                     /* slots of a stack the first walk launch of a level uses (< stack_cap: tests) */
+    uint32_t stack_use;                                     /* slots of a stack every pass but the last uses (< stack_cap: tests) */
     uint32_t* counts;
     const uint32_t* prev_children;
     unsigned grid;                                          /* workgroups of the persistent kernels */
     unsigned shade_grid;                                    /* workgroups of k_shade */
     uint32_t fetch_walk, fetch_hard;                        /* input items a wave reserves per cursor atomic */
+    uint32_t private_limit;                                 /* generations of at most this many rays are finished on private stacks */
 };
 
-/* one launch of the specular walk.  n_cam > 0: the fresh input are the camera rays of positions [ base, base + n_cam );
- * n_cam == 0: the ray queue rays_a (mop == false) or the overflow queue rays_b of the launch before (mop == true) */
-void acn_launch_walk( KernelFlags f, bool mop, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
+/* pass `pass` of the specular walk of the level.  n_cam > 0 (pass 0 of level 0): the input are the camera rays of
+ * positions [ base, base + n_cam ); else generation `pass` of the level's ray queues.  last: the input is finished on the
+ * private stacks whatever its size. */
+void acn_launch_walk( KernelFlags f, uint32_t pass, bool last, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
                       const double* pos_xy, size_t first_pixel, uint32_t base, uint32_t n_cam,
                       unsigned long long* accum, unsigned long long* counters );
 void acn_launch_shade_hits( bool count, const LevelQ& q, hipStream_t stream, const SceneArgs& s,
@@ -58,21 +60,12 @@ void acn_launch_hard_path( KernelFlags f, const LevelQ& q, size_t lds_bytes, hip
 #define ACN_SCENE_ARGS_OF( s ) ( s ).dev, ( s ).nodes, ( s ).mats, ( s ).elems, ( s ).textures
 #define ACN_TASKQ_ARGS_OF( q ) ( q ).tasks, ( q ).idx[ 0 ], ( q ).idx[ 1 ], ( q ).idx[ 2 ], ( q ).idx[ 3 ], ( q ).counts, ( q ).task_cap
 
-/* k_walk< C, L, R > for the three kinds of fresh input */
-#define ACN_LW_( C, L, R ) do { \
-    if( n_cam ) \
-        hipLaunchKernelGGL( ( k_walk< C, L, R > ), dim3( q.grid ), dim3( 256 ), lds_bytes, stream, ACN_SCENE_ARGS_OF( s ), ACN_TASKQ_ARGS_OF( q ), \
-            ( const RayTask* )nullptr, ( const uint32_t* )nullptr, 0u, pos_xy, first_pixel, base, n_cam, \
-            ( uint32_t )QC_CUR_WALK, ( uint32_t )QC_RAYS_OVF, q.rays_b, q.ray_cap, q.stacks, q.stack_cap, q.stack_use, q.fetch_walk, accum, counters ); \
-    else if( !mop ) \
-        hipLaunchKernelGGL( ( k_walk< C, L, R > ), dim3( q.grid ), dim3( 256 ), lds_bytes, stream, ACN_SCENE_ARGS_OF( s ), ACN_TASKQ_ARGS_OF( q ), \
-            ( const RayTask* )q.rays_a, ( const uint32_t* )( q.counts + QC_RAYS ), q.ray_cap, ( const double* )nullptr, ( size_t )0, 0u, 0u, \
-            ( uint32_t )QC_CUR_WALK, ( uint32_t )QC_RAYS_OVF, q.rays_b, q.ray_cap, q.stacks, q.stack_cap, q.stack_use, q.fetch_walk, accum, counters ); \
-    else \
-        hipLaunchKernelGGL( ( k_walk< C, L, R > ), dim3( q.grid ), dim3( 256 ), lds_bytes, stream, ACN_SCENE_ARGS_OF( s ), ACN_TASKQ_ARGS_OF( q ), \
-            ( const RayTask* )q.rays_b, ( const uint32_t* )( q.counts + QC_RAYS_OVF ), q.ray_cap, ( const double* )nullptr, ( size_t )0, 0u, 0u, \
-            ( uint32_t )QC_CUR_MOP, ( uint32_t )QC_RAYS_OVF2, ( RayTask* )nullptr, 0u, q.stacks, q.stack_cap, q.stack_cap, q.fetch_walk, accum, counters ); \
-    } while( 0 )
+/* k_walk< C, L, R > */
+#define ACN_LW_( C, L, R ) \
+    hipLaunchKernelGGL( ( k_walk< C, L, R > ), dim3( q.grid ), dim3( 256 ), lds_bytes, stream, ACN_SCENE_ARGS_OF( s ), ACN_TASKQ_ARGS_OF( q ), \
+        n_cam ? ( const RayTask* )nullptr : ( const RayTask* )q.rays[ pass & 1 ], q.ray_cap, pass, pos_xy, first_pixel, base, n_cam, \
+        q.rays[ ( pass + 1 ) & 1 ], q.ray_cap, last ? 0xFFFFFFFFu : q.private_limit, \
+        q.stacks, q.stack_cap, last ? q.stack_cap : q.stack_use, q.fetch_walk, accum, counters )
 
 /* body of acn_launch_shade<LPT>: shared by the four k_shade translation units */
 #define ACN_DEFINE_LAUNCH_SHADE( NAME, LPT, CLS ) \

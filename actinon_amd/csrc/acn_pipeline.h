@@ -154,16 +154,17 @@ struct HardPath
 #define ACN_INVALID 0xFFFFFFFFu
 #define ACN_NCLASS 4
 /* One counter block per path level (uint32 each), all blocks of a chunk zeroed by one memset before its first launch.
- * Queue counters are high-water marks of reserved slots (dead slots included); QS_* are exact statistics. */
+ * Queue counters are high-water marks of reserved slots (dead slots included); QS_* are exact statistics.
+ * QC_GEN + g: rays waiting for walk pass g of the level (g = 0: filled by k_shade_hits; g > 0: by pass g - 1);
+ * QC_CUR_GEN + g: the work-fetch cursor of pass g. */
+#define ACN_MAX_WALK_PASSES 32
 enum
 {
     QC_TASKS = 0, QC_CLASS0 = 1, QC_CHILDREN = 5, QC_FLAGS = 6, QC_HARD_SHADOW = 7, QC_HARD_PATH = 8,
-    QC_RAYS = 9,        /* ray queue filled by k_shade_hits, fresh input of k_walk at levels >= 1 */
-    QC_RAYS_OVF = 10,   /* rays that did not fit a wave's private stack: input of the mop-up launch of k_walk ... */
-    QC_RAYS_OVF2 = 11,  /* ... and what did not fit there (ACN_FLAG_CHILD_OVERFLOW is raised with it) */
-    QC_CUR_WALK = 12, QC_CUR_MOP = 13, QC_CUR_HS = 14, QC_CUR_HP = 15, QC_CUR_HITS = 16,   /* work-fetch cursors */
-    QS_WALK_RAYS = 17, QS_HARD_SHADOW = 18, QS_HARD_PATH = 19, QS_CHILDREN = 20, QS_TASKS = 21, QS_WALK_STEPS = 22,
-    QC_N = 24
+    QC_CUR_HS = 9, QC_CUR_HP = 10, QC_CUR_HITS = 11,
+    QS_WALK_RAYS = 12, QS_HARD_SHADOW = 13, QS_HARD_PATH = 14, QS_CHILDREN = 15, QS_TASKS = 16, QS_WALK_STEPS = 17, QS_PRIVATE_RAYS = 18,
+    QC_GEN = 32, QC_CUR_GEN = QC_GEN + ACN_MAX_WALK_PASSES + 1,
+    QC_N = 104
 };
 
 #ifndef ACN_CLASS0_MIN
@@ -195,30 +196,33 @@ DEV void chunks_init( ChunkP cs )
     if( ( threadIdx.x & 63 ) < ACN_NCHUNKS ) { cs[ threadIdx.x & 63 ].cur = 0; cs[ threadIdx.x & 63 ].end = 0; }
 }
 
-/* every lane with `want` gets a distinct slot of the queue counted by *counter; kill( k ) marks slot k dead */
-template< class KILL >
-DEV uint32_t chunk_alloc( ChunkP cs, uint32_t* counter, uint32_t cap, bool want, KILL kill )
+/* every lane with `want` gets a distinct slot of the queue counted by *counter.  A request that does not fit the rest
+ * of the wave's reservation uses that rest up and continues in a new one, so slots only die at the end of a kernel. */
+DEV uint32_t chunk_alloc( ChunkP cs, uint32_t* counter, bool want )
 {
     unsigned long long mask = __ballot( want );
     if( !want ) return ACN_INVALID;
     int lane = ( int )( threadIdx.x & 63 );
     int leader = __builtin_amdgcn_readfirstlane( __ffsll( ( long long )mask ) - 1 );
     uint32_t m = ( uint32_t )__popcll( mask );
-    uint32_t base = 0;
+    uint32_t base = 0, room = 0, base2 = 0;
     if( lane == leader )
     {
         uint32_t cur = cs->cur, end = cs->end;
-        if( cur + m > end )
+        base = cur; room = end - cur;
+        if( m > room )
         {
-            for( uint32_t k = cur; k < end; k++ ) if( k < cap ) kill( k );
-            cur = atomicAdd( counter, ( uint32_t )ACN_QCHUNK );
-            cs->end = cur + ACN_QCHUNK;
+            base2 = atomicAdd( counter, ( uint32_t )ACN_QCHUNK );
+            cs->end = base2 + ACN_QCHUNK;
+            cs->cur = base2 + ( m - room );
         }
-        cs->cur = cur + m;
-        base = cur;
+        else cs->cur = cur + m;
     }
-    base = ( uint32_t )__builtin_amdgcn_readlane( ( int )base, leader );
-    return base + ( uint32_t )__popcll( mask & ( ( 1ull << lane ) - 1ull ) );
+    base  = ( uint32_t )__builtin_amdgcn_readlane( ( int )base, leader );
+    room  = ( uint32_t )__builtin_amdgcn_readlane( ( int )room, leader );
+    base2 = ( uint32_t )__builtin_amdgcn_readlane( ( int )base2, leader );
+    uint32_t rank = ( uint32_t )__popcll( mask & ( ( 1ull << lane ) - 1ull ) );
+    return rank < room ? base + rank : base2 + ( rank - room );
 }
 
 /* end of a kernel (all lanes of the wave): the unused tail of the wave's last reservation is dead */
@@ -289,7 +293,7 @@ struct TaskQ
     uint32_t  task_cap;
 };
 
-/* a ray queue in global memory (k_shade_hits -> k_walk; private-stack overflow of k_walk) */
+/* a ray queue in global memory (k_shade_hits -> k_walk; generation g -> generation g + 1 of k_walk) */
 struct RayQ
 {
     RayTask*  rays;
@@ -300,8 +304,7 @@ struct RayQ
 
     DEV void push( bool want, V3 p, V3 d, V3 T, double intensity, int depth, uint32_t pixel ) const
     {
-        RayTask* r = rays;
-        uint32_t slot = chunk_alloc( cs, counter, cap, want, [ r ]( uint32_t k ) { r[ k ].pixel = ACN_INVALID; } );
+        uint32_t slot = chunk_alloc( cs, counter, want );
         if( want )
         {
             if( slot < cap )
@@ -319,16 +322,23 @@ struct RayQ
     }
 };
 
-/* the private LIFO stack of a k_walk wave; `top` is the same in all lanes (every lane of the wave calls push) */
-struct RayStack
+/* Where a k_walk wave puts the specular children of its rays.  `priv` is the same in every wave of a launch:
+ *   false  generation pass: children go to the global queue of the next generation (the next launch spreads them
+ *          over the whole chip again);
+ *   true   the input is small: children go onto the wave's private LIFO stack and are traced by the same wave in its
+ *          next steps; what does not fit the stack joins the next generation's queue.
+ * `top` is the same in all lanes (every lane of the wave calls push). */
+struct WalkSink
 {
+    bool      priv;
     RayTask*  stack;
     uint32_t  cap;
     uint32_t  top;
-    RayQ      ovf;       /* what does not fit goes to the mop-up launch */
+    RayQ      out;
 
     DEV void push( bool want, V3 p, V3 d, V3 T, double intensity, int depth, uint32_t pixel )
     {
+        if( !priv ) { out.push( want, p, d, T, intensity, depth, pixel ); return; }
         unsigned long long mask = __ballot( want );
         uint32_t slot = top + ( uint32_t )__popcll( mask & ( ( 1ull << ( threadIdx.x & 63 ) ) - 1ull ) );
         uint32_t new_top = top + ( uint32_t )__popcll( mask );
@@ -339,7 +349,7 @@ struct RayStack
             c.p = p; c.d = d; c.T = T; c.intensity = intensity; c.depth = depth; c.pixel = pixel;
         }
         top = new_top < cap ? new_top : cap;
-        if( new_top > cap ) ovf.push( want && !fits, p, d, T, intensity, depth, pixel );   /* wave-uniform branch */
+        if( new_top > cap ) out.push( want && !fits, p, d, T, intensity, depth, pixel );   /* wave-uniform branch */
     }
 };
 
@@ -441,7 +451,7 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
     bool emit = diffuse && ( n_direct | n_path ) != 0;
     {
         /* task slots need no dead marks: tasks are only reached through the index lists */
-        uint32_t slot = chunk_alloc( tcs, &tq.counts[ QC_TASKS ], tq.task_cap, emit, []( uint32_t ) {} );
+        uint32_t slot = chunk_alloc( tcs, &tq.counts[ QC_TASKS ], emit );
         bool ok = emit && slot < tq.task_cap;
         if( emit && !ok ) atomicOr( &tq.counts[ QC_FLAGS ], ACN_FLAG_TASK_OVERFLOW );
         int cls = ok ? size_class( n_direct > n_path ? n_direct : n_path ) : -1;
@@ -463,7 +473,7 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
         for( int k = 0; k < ACN_NCLASS; k++ )
         {
             uint32_t* list = tq.idx[ k ];
-            uint32_t is = chunk_alloc( tcs + 1 + k, &tq.counts[ QC_CLASS0 + k ], tq.task_cap, cls == k, [ list ]( uint32_t j ) { list[ j ] = ACN_INVALID; } );
+            uint32_t is = chunk_alloc( tcs + 1 + k, &tq.counts[ QC_CLASS0 + k ], cls == k );
             if( cls == k )
             {
                 if( is < tq.task_cap ) list[ is ] = slot;
@@ -542,20 +552,31 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
 #define ACN_WALK_MAX_STEPS ( 1u << 20 )   /* safety bound of a wave's step loop (64 M rays per wave) */
 #endif
 
-/* The specular walk of one path level in ONE launch of persistent waves (see the head of this file).
- * Fresh input: rays_in == nullptr: the camera rays of sample positions [ base, base + n_cam ) of the call
- * (lum_machine_s_func, scene.c:976-1011); else the ray queue rays_in[ 0 .. min( *n_in_ptr, in_cap ) ).
- * cur_slot / ovf_slot: indices into the level's counter block of the fetch cursor and of the overflow queue's counter.
- * stacks: ( waves of the grid ) x stack_stride private ray slots, of which a wave uses stack_cap. */
+/* One pass of the specular walk of a path level: persistent waves, work fetched through the atomic cursor of the pass.
+ * Input (generation `pass` of the level): rays_in == nullptr: the camera rays of sample positions [ base, base + n_cam )
+ * of the call (lum_machine_s_func, scene.c:976-1011); else the ray queue rays_in[ 0 .. min( p_counts[ QC_GEN + pass ], in_cap ) ).
+ * Each ray is traced (scene_s_trans_hit) and its hit shaded: light / background terms go to the pixel, the diffuse block
+ * becomes a DTask, and the Fresnel / chromatic / refraction children go
+ *   - input larger than private_limit: to rays_out, the queue of generation pass + 1 -- the next launch deals them to
+ *     the whole chip again (no wave follows a long chain alone while the others idle);
+ *   - else: onto the wave's private LIFO stack (stacks: ( waves of the grid ) x stack_stride slots, stack_cap of them
+ *     used); the wave works in steps of 64 rays -- the top of its stack, topped up with fresh input -- until both are
+ *     empty, so the tail of a level, up to trace_depth generations of a few rays each, costs no further launch.  Rays
+ *     that do not fit the stack join rays_out.
+ * The host enqueues a fixed number of passes per level blind; passes whose input is empty exit at once. */
 template< bool COUNT, bool LDS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_TRACE_WAVES )
-void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ rays_in, const uint32_t* __restrict__ n_in_ptr, uint32_t in_cap,
+void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ rays_in, uint32_t in_cap, uint32_t pass,
              const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n_cam,
-             uint32_t cur_slot, uint32_t ovf_slot, RayTask* __restrict__ ovf_rays, uint32_t ovf_cap,
+             RayTask* __restrict__ rays_out, uint32_t out_cap, uint32_t private_limit,
              RayTask* __restrict__ stacks, uint32_t stack_stride, uint32_t stack_cap, uint32_t fetch_batch,
              unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_CHUNK_STATES
+    uint32_t n_in = n_cam;
+    if( rays_in ) { n_in = p_counts[ QC_GEN + pass ]; n_in = n_in < in_cap ? n_in : in_cap; }
+    n_in = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n_in );
+    if( n_in == 0 ) return;
     ACN_SCENE_VIEW
     ACN_TASKQ_VIEW
     if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
@@ -566,30 +587,28 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
     cnt.clear();
     const int lane = ( int )( threadIdx.x & 63 );
     const uint32_t wave = blockIdx.x * ( blockDim.x >> 6 ) + ( threadIdx.x >> 6 );
-    uint32_t n_in = n_cam;
-    if( rays_in ) { n_in = *n_in_ptr; n_in = n_in < in_cap ? n_in : in_cap; }
-    n_in = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n_in );
-    RayStack st;
-    st.stack = stacks + ( size_t )wave * stack_stride; st.cap = stack_cap; st.top = 0;
-    st.ovf.rays = ovf_rays; st.ovf.counter = p_counts + ovf_slot; st.ovf.cap = ovf_cap; st.ovf.flags = p_counts + QC_FLAGS; st.ovf.cs = cs + 5;
-    uint32_t* cursor = p_counts + cur_slot;
+    WalkSink sink;
+    sink.priv = n_in <= private_limit;
+    sink.stack = stacks + ( size_t )wave * stack_stride; sink.cap = stack_cap; sink.top = 0;
+    sink.out.rays = rays_out; sink.out.counter = p_counts + QC_GEN + pass + 1; sink.out.cap = out_cap; sink.out.flags = p_counts + QC_FLAGS; sink.out.cs = cs + 5;
+    uint32_t* cursor = p_counts + QC_CUR_GEN + pass;
     FetchRange fr;
-    fr.cur = fr.end = 0; fr.more = n_in > 0;
+    fr.cur = fr.end = 0; fr.more = true;
     uint32_t traced = 0, steps = 0;
     bool finished = false;
     for( uint32_t step = 0; step < ACN_WALK_MAX_STEPS; step++ )
     {
         /* the step's 64 rays: the top of the private stack, topped up with fresh input */
-        uint32_t n_pop = st.top < 64u ? st.top : 64u;
+        uint32_t n_pop = sink.top < 64u ? sink.top : 64u;
         uint32_t n_fresh = 0, fb = 0;
         if( n_pop < 64u ) n_fresh = range_take( fr, cursor, fetch_batch, n_in, 64u - n_pop, &fb );
         if( n_pop + n_fresh == 0 ) { finished = true; break; }
-        st.top -= n_pop;
+        sink.top -= n_pop;
         const RayTask* src = nullptr;
         bool live = false;
         uint32_t pixel = 0;
         V3 rp = mk( 0, 0, 0 ), rd = mk( 0, 0, 1 );
-        if( ( uint32_t )lane < n_pop ) { src = st.stack + st.top + lane; live = true; }
+        if( ( uint32_t )lane < n_pop ) { src = sink.stack + sink.top + lane; live = true; }
         else if( ( uint32_t )lane < n_pop + n_fresh )
         {
             uint32_t i = fb + ( ( uint32_t )lane - n_pop );
@@ -632,7 +651,7 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
         bool hit = live && offs < F3_INF;
         V3 acc = mk( 0, 0, 0 );
         if( live && !hit ) acc = v_mld( T, v_mlf( ld3( sc.prm.background_color ), intensity ) );
-        shade_hit( sc, st, tq, cs, rp, rd, hit ? offs : 0.0, trans, hit ? depth : 0, intensity, T, pixel, acc, &cnt );
+        shade_hit( sc, sink, tq, cs, rp, rd, hit ? offs : 0.0, trans, hit ? depth : 0, intensity, T, pixel, acc, &cnt );
         if( live ) pixel_add( accum, sc.flags, pixel, acc );
         /* the wave reads next what it wrote last: same wave, program order; the fence keeps the compiler from moving the
          * next step's loads above this step's stores */
@@ -640,9 +659,10 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
     }
     /* the step bound is a safety net against a loop that does not end; work would be lost, so the call fails */
     if( !finished && lane == 0 ) atomicOr( p_counts + QC_FLAGS, ACN_FLAG_STACK_OVERFLOW );
-    st.ovf.close();
+    sink.out.close();
     task_chunks_close( tq, cs );
     wave_stat_add( p_counts + QS_WALK_RAYS, traced );
+    if( sink.priv ) wave_stat_add( p_counts + QS_PRIVATE_RAYS, traced );
     if( lane == 0 && steps ) atomicAdd( p_counts + QS_WALK_STEPS, steps );
     wave_add_counters( counters, cnt );
 }
@@ -666,7 +686,7 @@ void k_shade_hits( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const HitRec* __restrict_
     n = n < rec_cap ? n : rec_cap;
     n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
     RayQ rq;
-    rq.rays = rays_out; rq.counter = p_counts + QC_RAYS; rq.cap = ray_cap; rq.flags = p_counts + QC_FLAGS; rq.cs = cs + 5;
+    rq.rays = rays_out; rq.counter = p_counts + QC_GEN; rq.cap = ray_cap; rq.flags = p_counts + QC_FLAGS; rq.cs = cs + 5;
     FetchRange fr;
     fr.cur = fr.end = 0; fr.more = n > 0;
     for( ;; )
@@ -798,7 +818,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 int occ = root_occluded_fast( scp, sc.matter_root, pos, out_d, a, &cnt );
                 if( occ == 0 ) s += c;
                 /* hard shadow rays: appended to the queue of k_hard_shadow, which adds c itself if unoccluded */
-                uint32_t hs = chunk_alloc( cs + 0, &p_counts[ QC_HARD_SHADOW ], hard_cap, occ == 2, kill_hs );
+                uint32_t hs = chunk_alloc( cs + 0, &p_counts[ QC_HARD_SHADOW ], occ == 2 );
                 if( occ == 2 )
                 {
                     if( hs < hard_cap )
@@ -853,7 +873,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 bool hit = live && !hard && a < sc.prm.max_path_length;
                 if( live && !hard && !hit ) bsum += weight * diffuse_intensity;
                 /* hard path rays: the transition hit is finished by k_hard_path */
-                uint32_t hp = chunk_alloc( cs + 1, &p_counts[ QC_HARD_PATH ], hard_cap, hard, kill_hp );
+                uint32_t hp = chunk_alloc( cs + 1, &p_counts[ QC_HARD_PATH ], hard );
                 if( hard )
                 {
                     if( hp < hard_cap )
@@ -869,7 +889,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                     }
                 }
                 /* the surviving path rays: the next level's queue */
-                uint32_t csl = chunk_alloc( cs + 2, &p_counts[ QC_CHILDREN ], child_cap, hit, kill_ch );
+                uint32_t csl = chunk_alloc( cs + 2, &p_counts[ QC_CHILDREN ], hit );
                 if( hit )
                 {
                     if( csl < child_cap )
@@ -982,7 +1002,7 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
                 pixel_add( accum, sc.flags, r.pixel, v_mld( r.T, c ) );
             }
         }
-        uint32_t csl = chunk_alloc( cs + 0, &p_counts[ QC_CHILDREN ], child_cap, hit, kill_ch );
+        uint32_t csl = chunk_alloc( cs + 0, &p_counts[ QC_CHILDREN ], hit );
         if( hit )
         {
             if( csl < child_cap )

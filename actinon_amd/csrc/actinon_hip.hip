@@ -77,9 +77,11 @@ struct Tunables
     unsigned grid = 0;                 /* ACN_GRID: workgroups of the persistent kernels, 0 = 4 per compute unit */
     unsigned shade_grid = 0;           /* ACN_SHADE_GRID: workgroups of k_shade, 0 = 4 per compute unit */
     uint32_t stack_cap = 512;          /* ACN_STACK_CAP: private ray slots per k_walk wave */
-    uint32_t fetch_walk = 256;         /* ACN_FETCH_WALK: fresh rays a k_walk wave reserves per cursor atomic */
+    uint32_t fetch_walk = 64;          /* ACN_FETCH_WALK: fresh rays a k_walk wave reserves per cursor atomic */
+    uint32_t walk_passes = 12;         /* ACN_WALK_PASSES: launches of k_walk per path level (the last one finishes whatever is left) */
+    uint32_t private_limit = 32768;    /* ACN_PRIVATE_LIMIT: a generation of at most this many rays is finished on private stacks */
     uint32_t fetch_hard = 256;         /* ACN_FETCH_HARD: records a wave of the hard-ray kernels / k_shade_hits reserves per atomic */
-    uint32_t stack_use = 0;            /* ACN_TEST_STACK_USE: slots the first walk launch of a level uses (tests of the mop-up launch) */
+    uint32_t stack_use = 0;            /* ACN_TEST_STACK_USE: slots of a private stack every walk pass but the last uses (tests of the overflow path) */
     bool     count_work = false;       /* ACN_COUNT_WORK */
     bool     stage_timing = false;     /* ACN_STAGE_TIMING */
     void read()
@@ -93,6 +95,10 @@ struct Tunables
         if( const char* e = getenv( "ACN_TEST_STACK_USE" ) ) stack_use = ( uint32_t )atoll( e );
         if( const char* e = getenv( "ACN_FETCH_WALK" ) ) fetch_walk = ( uint32_t )atoll( e );
         if( const char* e = getenv( "ACN_FETCH_HARD" ) ) fetch_hard = ( uint32_t )atoll( e );
+        if( const char* e = getenv( "ACN_WALK_PASSES" ) ) walk_passes = ( uint32_t )atoll( e );
+        if( const char* e = getenv( "ACN_PRIVATE_LIMIT" ) ) private_limit = ( uint32_t )atoll( e );
+        if( walk_passes < 1 ) walk_passes = 1;
+        if( walk_passes > ACN_MAX_WALK_PASSES ) walk_passes = ACN_MAX_WALK_PASSES;
         if( fetch_walk < 64 ) fetch_walk = 64;
         if( fetch_hard < 64 ) fetch_hard = 64;
         count_work = getenv( "ACN_COUNT_WORK" ) != nullptr;
@@ -147,7 +153,7 @@ struct acn_scene_handle
     bool leaf_lights = true;                   /* every light element is a plane / sphere */
     bool count_work = false;                   /* ACN_OPT_COUNT_WORK of the current call */
     uint64_t launches[ 4 ] = { 0, 0, 0, 0 };   /* walk, shade, finalize, hard-ray kernels */
-    uint64_t hard_rays = 0, walk_steps = 0, walk_rays = 0, shade_hit_recs = 0, host_syncs = 0;
+    uint64_t hard_rays = 0, walk_steps = 0, walk_rays = 0, shade_hit_recs = 0, host_syncs = 0, private_rays = 0;
     uint32_t flags_seen = 0;                   /* ACN_FLAG_* bits of the last call */
     double recs_per_pos = 0;                   /* learned: the fullest queue's records per sample position (chunk sizing) */
     uint64_t chunks = 0, retries = 0, levels = 0;
@@ -877,21 +883,30 @@ static LevelQ level_queues( const acn_scene_handle* h, int level )
     q.tasks = w.tasks; for( int k = 0; k < ACN_NCLASS; k++ ) q.idx[ k ] = w.idx[ k ];
     q.task_cap = q.child_cap = q.hard_cap = q.ray_cap = w.cap;
     q.children = w.children; q.hard_shadow = w.hard_shadow; q.hard_path = w.hard_path;
-    q.rays_a = w.rays[ 0 ]; q.rays_b = w.rays[ 1 ];
+    q.rays[ 0 ] = w.rays[ 0 ]; q.rays[ 1 ] = w.rays[ 1 ];
     q.stacks = w.stacks; q.stack_cap = h->tun.stack_cap; q.stack_use = h->tun.stack_use;
     q.counts = h->d_counts + ( size_t )level * QC_N;
     q.prev_children = h->d_counts + ( size_t )( level > 0 ? level - 1 : 0 ) * QC_N + QC_CHILDREN;
     q.grid = h->grid; q.shade_grid = h->shade_grid;
-    q.fetch_walk = h->tun.fetch_walk; q.fetch_hard = h->tun.fetch_hard;
+    q.fetch_walk = h->tun.fetch_walk; q.fetch_hard = h->tun.fetch_hard; q.private_limit = h->tun.private_limit;
     return q;
 }
 static size_t machine_lds_bytes( const acn_scene_handle* h ) { return h->lds_bytes + h->lds_stack_bytes; }
 
+/* launches of k_walk for path level `level`: ACN_WALK_PASSES, but no more than the hits of the level have depth left */
+static uint32_t walk_passes_of_level( const acn_scene_handle* h, int level )
+{
+    const uint64_t depth_left = h->dev.prm.trace_depth > 10ull * ( uint64_t )level ? h->dev.prm.trace_depth - 10ull * ( uint64_t )level : 1;
+    uint32_t passes = h->tun.walk_passes;
+    if( passes > depth_left + 1 ) passes = ( uint32_t )depth_left + 1;
+    return passes;
+}
+
 #define ACN_LAUNCH( h, stage, stream, call ) do { int st_ = stage_begin( h, stage, stream ); if( st_ != ACN_OK ) return st_; call; \
     HIP_TRY( hipGetLastError() ); if( ( st_ = stage_end( h, stream ) ) != ACN_OK ) return st_; } while( 0 )
 
-/* One chunk of positions [ base, base + cnt ).  The whole chain -- per path level: ( k_shade_hits -> ) k_walk -> its
- * mop-up launch -> k_shade x 4 size classes -> k_hard_shadow -> k_hard_path -- is enqueued blind: every kernel takes
+/* One chunk of positions [ base, base + cnt ).  The whole chain -- per path level: ( k_shade_hits -> ) the passes of
+ * k_walk -> k_shade x 4 size classes -> k_hard_shadow -> k_hard_path -- is enqueued blind: every kernel takes
  * its input count from the counter block of its level on the device, and a level that turns out to be empty costs a few
  * launches of waves that exit at once.  The host synchronises ONCE, at the end, to read the counter blocks: overflow
  * flags (the chunk is then redone smaller) and statistics. */
@@ -908,17 +923,14 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
     for( int level = 0; level < levels; level++ )
     {
         const LevelQ q = level_queues( h, level );
-        if( level == 0 )
-        {
-            ACN_LAUNCH( h, 0, stream, acn_launch_walk( f, false, q, lds, stream, s, d_pos_xy, first_pixel, base, cnt, h->d_accum, h->d_counters ) );
-        }
-        else
-        {
-            /* the path-sample hits of the level before are shaded, then their specular rays walked */
-            ACN_LAUNCH( h, 0, stream, acn_launch_shade_hits( f.count, q, stream, s, h->d_accum, h->d_counters ) );
-            ACN_LAUNCH( h, 0, stream, acn_launch_walk( f, false, q, lds, stream, s, nullptr, 0, 0, 0, h->d_accum, h->d_counters ) );
-        }
-        ACN_LAUNCH( h, 0, stream, acn_launch_walk( f, true, q, lds, stream, s, nullptr, 0, 0, 0, h->d_accum, h->d_counters ) );
+        /* the path-sample hits of the level before are shaded (level >= 1), then the specular rays walked: generation
+         * passes while the generations are large, the rest on the waves' private stacks (k_walk); a level has at most as
+         * many generations as its hits have depth left */
+        if( level > 0 ) ACN_LAUNCH( h, 0, stream, acn_launch_shade_hits( f.count, q, stream, s, h->d_accum, h->d_counters ) );
+        const uint32_t passes = walk_passes_of_level( h, level );
+        for( uint32_t pass = 0; pass < passes; pass++ )
+            ACN_LAUNCH( h, 0, stream, acn_launch_walk( f, pass, pass + 1 == passes, q, lds, stream, s, d_pos_xy, first_pixel, base,
+                                                       level == 0 && pass == 0 ? cnt : 0u, h->d_accum, h->d_counters ) );
         ACN_LAUNCH( h, 1, stream, acn_launch_shade64( f, q, stream, s, h->d_accum, h->d_counters ) );
         ACN_LAUNCH( h, 1, stream, acn_launch_shade16( f, q, stream, s, h->d_accum, h->d_counters ) );
         ACN_LAUNCH( h, 1, stream, acn_launch_shade4( f, q, stream, s, h->d_accum, h->d_counters ) );
@@ -935,7 +947,7 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
     {
         const uint32_t* c = h->h_counts + ( size_t )level * QC_N;
         flags |= c[ QC_FLAGS ];
-        if( c[ QC_RAYS_OVF2 ] ) flags |= ACN_FLAG_CHILD_OVERFLOW;   /* rays left over by the mop-up launch */
+        if( c[ QC_GEN + walk_passes_of_level( h, level ) ] ) flags |= ACN_FLAG_CHILD_OVERFLOW;   /* rays left over by the last pass */
     }
     h->flags_seen |= flags & ACN_FLAG_CLAMPED;
     if( flags & ACN_FLAG_STACK_OVERFLOW ) return fail( ACN_ERR_UNSUPPORTED, "device CSG / compound stack overflow (or a walk that did not end)" );
@@ -952,8 +964,10 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
         if( c[ QC_TASKS ] > h->peak_tasks ) h->peak_tasks = c[ QC_TASKS ];
         if( c[ QC_CHILDREN ] > h->peak_children ) h->peak_children = c[ QC_CHILDREN ];
         /* the fullest queue of the chunk: what the next chunk's size is derived from */
-        const int q_slots[] = { QC_TASKS, QC_CLASS0, QC_CLASS0 + 1, QC_CLASS0 + 2, QC_CLASS0 + 3, QC_CHILDREN, QC_HARD_SHADOW, QC_HARD_PATH, QC_RAYS, QC_RAYS_OVF };
+        const int q_slots[] = { QC_TASKS, QC_CLASS0, QC_CLASS0 + 1, QC_CLASS0 + 2, QC_CLASS0 + 3, QC_CHILDREN, QC_HARD_SHADOW, QC_HARD_PATH };
         for( int k : q_slots ) if( c[ k ] > *fullest ) *fullest = c[ k ];
+        for( int g = 0; g <= ACN_MAX_WALK_PASSES; g++ ) if( c[ QC_GEN + g ] > *fullest ) *fullest = c[ QC_GEN + g ];
+        h->private_rays += c[ QS_PRIVATE_RAYS ];
     }
     return ACN_OK;
 }
@@ -978,7 +992,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     }
     h->events_used = 0;
     h->launches[ 0 ] = h->launches[ 1 ] = h->launches[ 2 ] = h->launches[ 3 ] = 0;
-    h->hard_rays = 0; h->walk_steps = 0; h->walk_rays = 0; h->shade_hit_recs = 0; h->host_syncs = 0; h->flags_seen = 0;
+    h->hard_rays = 0; h->walk_steps = 0; h->walk_rays = 0; h->shade_hit_recs = 0; h->host_syncs = 0; h->flags_seen = 0; h->private_rays = 0;
     h->chunks = h->retries = h->levels = 0;
     h->peak_tasks = h->peak_children = 0;
     HIP_TRY( hipMemsetAsync( h->d_counters, 0, sizeof( unsigned long long ) * CNT_N, stream ) );
@@ -1016,14 +1030,13 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
         }
         h->chunks++;
         base += cnt;
-        if( !h->tun.chunk )
+        if( !h->tun.chunk && ( cnt >= 16384 || h->recs_per_pos == 0 ) )
         {
-            /* dead slots of the queue reservations ( <= 64 per wave and kernel ) do not scale with the chunk */
-            double slack = 64.0 * 4 * h->grid * 6;
-            double per_pos = ( ( double )fullest > slack ? ( double )fullest - slack : ( double )fullest * 0.25 ) / ( double )cnt;
+            /* (small chunks over-estimate: the dead slots at the ends of the waves' queue reservations do not scale) */
+            double per_pos = ( double )fullest / ( double )cnt;
             if( per_pos < 1e-3 ) per_pos = 1e-3;
             h->recs_per_pos = per_pos;
-            double next = 0.7 * ( cap - slack > 0 ? cap - slack : cap ) / per_pos;
+            double next = 0.7 * cap / per_pos;
             if( next > 2.0e9 ) next = 2.0e9;
             chunk = ( size_t )next;
             if( chunk < 64 ) chunk = 64;
@@ -1189,7 +1202,7 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
     /* statistics of the call: sums / maxima over the lanes */
     h->events_used = 0;
     h->launches[ 0 ] = h->launches[ 1 ] = h->launches[ 2 ] = h->launches[ 3 ] = 0;
-    h->hard_rays = h->walk_steps = h->walk_rays = h->shade_hit_recs = h->host_syncs = 0; h->flags_seen = 0;
+    h->hard_rays = h->walk_steps = h->walk_rays = h->shade_hit_recs = h->host_syncs = h->private_rays = 0; h->flags_seen = 0;
     h->chunks = h->retries = h->levels = 0;
     h->peak_tasks = h->peak_children = 0;
     for( int k = 0; k < lanes; k++ )
@@ -1198,7 +1211,7 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
         if( lane_count( n, lanes, k ) == 0 ) continue;
         for( int i = 0; i < 4; i++ ) h->launches[ i ] += l->launches[ i ];
         h->hard_rays += l->hard_rays; h->walk_steps += l->walk_steps; h->walk_rays += l->walk_rays; h->shade_hit_recs += l->shade_hit_recs;
-        h->host_syncs += l->host_syncs; h->flags_seen |= l->flags_seen;
+        h->host_syncs += l->host_syncs; h->flags_seen |= l->flags_seen; h->private_rays += l->private_rays;
         h->chunks += l->chunks; h->retries += l->retries;
         if( l->levels > h->levels ) h->levels = l->levels;
         h->peak_tasks += l->peak_tasks; h->peak_children += l->peak_children;
@@ -1291,7 +1304,7 @@ extern "C" int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms )
 
 extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
 {
-    if( !h || !out || n < 0 || n > 21 || !h->timed ) return fail( ACN_ERR_ARG, "no timed launch" );
+    if( !h || !out || n < 0 || n > 22 || !h->timed ) return fail( ACN_ERR_ARG, "no timed launch" );
     HIP_TRY( hipSetDevice( h->device ) );
     HIP_TRY( hipEventSynchronize( h->ev1 ) );
     double ms[ 4 ] = { 0, 0, 0, 0 };
@@ -1310,12 +1323,12 @@ extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
     }
     float total = 0;
     HIP_TRY( hipEventElapsedTime( &total, h->ev0, h->ev1 ) );
-    double v[ 21 ] = { ms[ 0 ], ms[ 1 ], ms[ 2 ], total, ( double )h->launches[ 0 ], ( double )h->launches[ 1 ], ( double )h->launches[ 2 ],
+    double v[ 22 ] = { ms[ 0 ], ms[ 1 ], ms[ 2 ], total, ( double )h->launches[ 0 ], ( double )h->launches[ 1 ], ( double )h->launches[ 2 ],
                        ( double )h->chunks, ( double )h->retries, ( double )h->levels, ( double )h->peak_tasks, ( double )h->peak_children,
                        ( double )queue_cap, ms[ 3 ], ( double )h->launches[ 3 ], ( double )h->hard_rays,
                        ( double )h->walk_rays, ( double )h->shade_hit_recs, ( double )h->host_syncs, ( double )h->walk_steps,
-                       ( double )h->flags_seen };
-    for( int k = 0; k < n && k < 21; k++ ) out[ k ] = v[ k ];
+                       ( double )h->flags_seen, ( double )h->private_rays };
+    for( int k = 0; k < n && k < 22; k++ ) out[ k ] = v[ k ];
     return ACN_OK;
 }
 

@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include "acn_launch.h"
 
-void acn_launch_walk_count( KernelFlags f, bool mop, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
+void acn_launch_walk_count( KernelFlags f, uint32_t pass, bool last, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
                             const double* pos_xy, size_t first_pixel, uint32_t base, uint32_t n_cam,
                             unsigned long long* accum, unsigned long long* counters )
 {
@@ -11,7 +11,7 @@ void acn_launch_walk_count( KernelFlags f, bool mop, const LevelQ& q, size_t lds
 }
 
 #define ACN_LSH_( C ) hipLaunchKernelGGL( ( k_shade_hits< C > ), dim3( q.grid ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS_OF( s ), ACN_TASKQ_ARGS_OF( q ), \
-    ( const HitRec* )q.children, q.prev_children, q.child_cap, q.fetch_hard, q.rays_a, q.ray_cap, accum, counters )
+    ( const HitRec* )q.children, q.prev_children, q.child_cap, q.fetch_hard, q.rays[ 0 ], q.ray_cap, accum, counters )
 void acn_launch_shade_hits( bool count, const LevelQ& q, hipStream_t stream, const SceneArgs& s,
                             unsigned long long* accum, unsigned long long* counters )
 {

@@ -215,7 +215,8 @@ int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms );
  * [13] hard-ray kernels ms, [14] their launches, [15] hard rays, [16] rays traced by the specular walk (camera rays
  * included), [17] path-sample hits shaded (levels >= 1), [18] host synchronisations inside the pipeline (one per chunk),
  * [19] 64-ray steps of the walk kernel's waves ([16] / ( 64 * [19] ) is its lane occupancy), [20] ACN_FLAG_* bits seen
- * (8: a pixel contribution exceeded the fixed-point clamp of 16384). n <= 21. */
+ * (8: a pixel contribution exceeded the fixed-point clamp of 16384), [21] rays the walk finished on the waves' private
+ * stacks instead of in generation passes. n <= 22. */
 int acn_last_stage_ms( acn_scene_handle* h, double* out, int n );
 
 /* Work counters of the last render call (rays cast, node visits ...), see DESIGN.md. n <= 16. */

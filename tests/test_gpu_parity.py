@@ -198,10 +198,11 @@ def test_many_spheres_with_gpu_auto_envelopes(oracle):
     assert np.abs(gpu - cpu).max() <= TOL
 
 
-def test_lanes_grid_and_mop_up_do_not_change_a_pixel(oracle, monkeypatch):
-    """Concurrent lanes (ACN_LANES), the size of the persistent grid (ACN_GRID) and the mop-up launch of the specular walk
-    (forced by letting the first walk launch use one slot of each wave's ray stack, ACN_TEST_STACK_USE) reorganise the
-    work, not the arithmetic: the frame is bit-identical in every arrangement and equals the oracle on a sample of pixels."""
+def test_lanes_grid_and_walk_arrangement_do_not_change_a_pixel(oracle, monkeypatch):
+    """Concurrent lanes (ACN_LANES), the size of the persistent grid (ACN_GRID), how the specular walk is cut into
+    generation passes and private-stack finishing (ACN_WALK_PASSES, ACN_PRIVATE_LIMIT) and the overflow of the private
+    stacks (forced by letting a pass use one slot of each wave's stack, ACN_TEST_STACK_USE) reorganise the work, not the
+    arithmetic: the frame is bit-identical in every arrangement and equals the oracle on a sample of pixels."""
     sc = A.Scene.build("wine_glass", image_width=320, image_height=180, path_samples=16, direct_samples=50)
     flat = sc.flatten()
     pos = S.positions(flat)
@@ -209,16 +210,21 @@ def test_lanes_grid_and_mop_up_do_not_change_a_pixel(oracle, monkeypatch):
     frames = {}
     for label, env in (("plain", dict(ACN_LANES="1")), ("lanes", dict(ACN_LANES="4")),
                        ("small_grid", dict(ACN_LANES="1", ACN_GRID="7", ACN_SHADE_GRID="5")),
-                       ("mop_up", dict(ACN_LANES="1", ACN_TEST_STACK_USE="1")),
-                       ("all", dict(ACN_LANES="3", ACN_GRID="96", ACN_TEST_STACK_USE="3"))):
-        for k in ("ACN_LANES", "ACN_GRID", "ACN_SHADE_GRID", "ACN_TEST_STACK_USE"):
+                       ("stack_overflow", dict(ACN_LANES="1", ACN_TEST_STACK_USE="1")),
+                       ("all_private", dict(ACN_LANES="1", ACN_WALK_PASSES="1")),
+                       ("all_generations", dict(ACN_LANES="1", ACN_WALK_PASSES="26", ACN_PRIVATE_LIMIT="0")),
+                       ("three_passes", dict(ACN_LANES="1", ACN_WALK_PASSES="3", ACN_PRIVATE_LIMIT="1000", ACN_FETCH_WALK="512")),
+                       ("all", dict(ACN_LANES="3", ACN_GRID="96", ACN_TEST_STACK_USE="3", ACN_PRIVATE_LIMIT="100000"))):
+        for k in ("ACN_LANES", "ACN_GRID", "ACN_SHADE_GRID", "ACN_TEST_STACK_USE", "ACN_WALK_PASSES", "ACN_PRIVATE_LIMIT", "ACN_FETCH_WALK"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)                 # read by acn_scene_upload
         h = A.Handle(flat)
         frames[label] = (h.render_positions(pos, linear=True), h.last_stages())
         h.close()
-    for label in ("lanes", "small_grid", "mop_up", "all"):
+    assert frames["all_private"][1]["private_rays"] == frames["plain"][1]["walk_rays"]
+    assert frames["all_generations"][1]["private_rays"] < frames["plain"][1]["private_rays"] < frames["plain"][1]["walk_rays"]
+    for label in ("lanes", "small_grid", "stack_overflow", "all_private", "all_generations", "three_passes", "all"):
         assert np.array_equal(frames[label][0], frames["plain"][0]), label
         assert frames[label][1]["walk_rays"] == frames["plain"][1]["walk_rays"], label
         assert frames[label][1]["hard_rays"] == frames["plain"][1]["hard_rays"], label
