@@ -42,7 +42,7 @@ struct LevelQ
  * positions [ base, base + n_cam ); else generation `pass` of the level's ray queues.  last: the input is finished on the
  * private stacks whatever its size. */
 void acn_launch_walk( KernelFlags f, uint32_t pass, bool last, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
-                      const double* pos_xy, size_t first_pixel, uint32_t base, uint32_t n_cam,
+                      const double* pos_xy, size_t first_pixel, uint32_t base, uint32_t n_cam, TileOrder order,
                       unsigned long long* accum, unsigned long long* counters );
 void acn_launch_shade_hits( bool count, const LevelQ& q, hipStream_t stream, const SceneArgs& s,
                             unsigned long long* accum, unsigned long long* counters );
@@ -63,7 +63,7 @@ void acn_launch_hard_path( KernelFlags f, const LevelQ& q, size_t lds_bytes, hip
 /* k_walk< C, L, R > */
 #define ACN_LW_( C, L, R ) \
     hipLaunchKernelGGL( ( k_walk< C, L, R > ), dim3( q.grid ), dim3( 256 ), lds_bytes, stream, ACN_SCENE_ARGS_OF( s ), ACN_TASKQ_ARGS_OF( q ), \
-        n_cam ? ( const RayTask* )nullptr : ( const RayTask* )q.rays[ pass & 1 ], q.ray_cap, pass, pos_xy, first_pixel, base, n_cam, \
+        n_cam ? ( const RayTask* )nullptr : ( const RayTask* )q.rays[ pass & 1 ], q.ray_cap, pass, pos_xy, first_pixel, base, n_cam, order, \
         q.rays[ ( pass + 1 ) & 1 ], q.ray_cap, last ? 0xFFFFFFFFu : q.private_limit, \
         q.stacks, q.stack_cap, last ? q.stack_cap : q.stack_use, q.fetch_walk, accum, counters )
 

@@ -552,9 +552,26 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
 #define ACN_WALK_MAX_STEPS ( 1u << 20 )   /* safety bound of a wave's step loop (64 M rays per wave) */
 #endif
 
+/* The order in which the sample positions of a call are worked off.  A chunk is a contiguous range of SLOTS; slot s
+ * stands for position  tile( s / 256 ) * 256 + s % 256  with  tile( t ) = t * mul mod n_tiles  (mul coprime to n_tiles:
+ * a bijection).  Tiles of 256 consecutive positions keep neighbouring pixels in one wave; the multiplicative stride
+ * spreads the tiles of any chunk over the whole frame, so that every chunk of a call sees the same mix of sky, floor
+ * and glass -- the queue fill of one chunk then predicts the next one's (launch_render sizes chunks that way). */
+struct TileOrder
+{
+    uint32_t n;         /* positions of the call */
+    uint32_t n_tiles;   /* ceil( n / 256 ) */
+    uint32_t mul;
+    DEV uint32_t position( uint32_t slot ) const
+    {
+        uint32_t tile = ( uint32_t )( ( ( uint64_t )( slot >> 8 ) * mul ) % n_tiles );
+        return ( tile << 8 ) + ( slot & 255u );
+    }
+};
+
 /* One pass of the specular walk of a path level: persistent waves, work fetched through the atomic cursor of the pass.
- * Input (generation `pass` of the level): rays_in == nullptr: the camera rays of sample positions [ base, base + n_cam )
- * of the call (lum_machine_s_func, scene.c:976-1011); else the ray queue rays_in[ 0 .. min( p_counts[ QC_GEN + pass ], in_cap ) ).
+ * Input (generation `pass` of the level): rays_in == nullptr: the camera rays of the sample positions in slots
+ * [ base, base + n_cam ) of the call's TileOrder (lum_machine_s_func, scene.c:976-1011); else the ray queue rays_in[ 0 .. min( p_counts[ QC_GEN + pass ], in_cap ) ).
  * Each ray is traced (scene_s_trans_hit) and its hit shaded: light / background terms go to the pixel, the diffuse block
  * becomes a DTask, and the Fresnel / chromatic / refraction children go
  *   - input larger than private_limit: to rays_out, the queue of generation pass + 1 -- the next launch deals them to
@@ -567,7 +584,7 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
 template< bool COUNT, bool LDS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_TRACE_WAVES )
 void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ rays_in, uint32_t in_cap, uint32_t pass,
-             const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n_cam,
+             const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n_cam, TileOrder order,
              RayTask* __restrict__ rays_out, uint32_t out_cap, uint32_t private_limit,
              RayTask* __restrict__ stacks, uint32_t stack_stride, uint32_t stack_cap, uint32_t fetch_batch,
              unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
@@ -615,8 +632,10 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
             if( rays_in ) { src = rays_in + i; live = src->pixel != ACN_INVALID; }
             else
             {
-                /* the camera ray of a sample position */
-                pixel = base + i;
+                /* the camera ray of a sample position (slots past the call's last position are empty) */
+                pixel = order.position( base + i );
+                live = pixel < order.n;
+                if( !live ) pixel = 0;
                 double mx, my;
                 if( pos_xy ) { mx = pos_xy[ ( size_t )pixel * 2 ]; my = pos_xy[ ( size_t )pixel * 2 + 1 ]; }
                 else
@@ -626,7 +645,6 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
                     my = ( double )( pix / sc.prm.image_width ) + 0.5;
                 }
                 camera_ray( sc, mx, my, &rp, &rd );
-                live = true;
             }
         }
         if( src && live ) { rp = src->p; rd = src->d; }

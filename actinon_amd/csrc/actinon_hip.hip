@@ -202,6 +202,16 @@ __global__ void k_finalize( const unsigned long long* __restrict__ accum, uint32
     out_rgb[ ( size_t )i * 3 + 2 ] = c.z;
 }
 
+/* the pixel sums of the positions in slots [ base, base + cnt ) start over (a chunk is redone after a queue overflow) */
+__global__ void k_clear_slots( unsigned long long* __restrict__ accum, uint32_t base, uint32_t cnt, TileOrder order )
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= cnt ) return;
+    uint32_t p = order.position( base + i );
+    if( p >= order.n ) return;
+    accum[ ( size_t )p * 3 + 0 ] = 0; accum[ ( size_t )p * 3 + 1 ] = 0; accum[ ( size_t )p * 3 + 2 ] = 0;
+}
+
 /* cl_s_sat + cps_from_cl after the (cross-GPU) accumulation */
 __global__ void k_resolve( const double* __restrict__ lin, size_t n, double gamma, double* __restrict__ out_rgb,
                            unsigned char* __restrict__ out_rgb8 )
@@ -910,7 +920,7 @@ static uint32_t walk_passes_of_level( const acn_scene_handle* h, int level )
  * its input count from the counter block of its level on the device, and a level that turns out to be empty costs a few
  * launches of waves that exit at once.  The host synchronises ONCE, at the end, to read the counter blocks: overflow
  * flags (the chunk is then redone smaller) and statistics. */
-static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t first_pixel, uint32_t base, uint32_t cnt,
+static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t first_pixel, uint32_t base, uint32_t cnt, TileOrder order,
                          hipStream_t stream, int* overflow, uint32_t* fullest )
 {
     *overflow = 0;
@@ -930,7 +940,7 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
         const uint32_t passes = walk_passes_of_level( h, level );
         for( uint32_t pass = 0; pass < passes; pass++ )
             ACN_LAUNCH( h, 0, stream, acn_launch_walk( f, pass, pass + 1 == passes, q, lds, stream, s, d_pos_xy, first_pixel, base,
-                                                       level == 0 && pass == 0 ? cnt : 0u, h->d_accum, h->d_counters ) );
+                                                       level == 0 && pass == 0 ? cnt : 0u, order, h->d_accum, h->d_counters ) );
         ACN_LAUNCH( h, 1, stream, acn_launch_shade64( f, q, stream, s, h->d_accum, h->d_counters ) );
         ACN_LAUNCH( h, 1, stream, acn_launch_shade16( f, q, stream, s, h->d_accum, h->d_counters ) );
         ACN_LAUNCH( h, 1, stream, acn_launch_shade4( f, q, stream, s, h->d_accum, h->d_counters ) );
@@ -1010,14 +1020,27 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     else chunk = ( size_t )( cap / ( ( double )( s + 2 ) * ( s > 16 ? ( double )s / 16.0 : 1.0 ) ) );
     if( h->tun.chunk ) chunk = h->tun.chunk;
     if( chunk < 64 ) chunk = 64;
+    /* the order of work: tiles of 256 positions in a multiplicative stride over the call (TileOrder) */
+    TileOrder order;
+    order.n = ( uint32_t )n;
+    order.n_tiles = ( uint32_t )( ( n + 255 ) / 256 );
+    order.mul = 1;
+    if( order.n_tiles > 2 )
+    {
+        auto gcd = []( uint64_t a, uint64_t b ) { while( b ) { uint64_t t = a % b; a = b; b = t; } return a; };
+        uint64_t m = ( uint64_t )( 0.6180339887 * order.n_tiles ) | 1u;
+        while( gcd( m, order.n_tiles ) != 1 ) m += 2;
+        order.mul = ( uint32_t )( m % order.n_tiles );
+    }
+    const size_t n_slots = ( size_t )order.n_tiles * 256;
     size_t base = 0;
-    while( base < n )
+    while( base < n_slots )
     {
         if( opts && opts->cancel && *opts->cancel ) return fail( ACN_ERR_CANCELLED, "cancelled" );
-        uint32_t cnt = ( uint32_t )( ( n - base < chunk ) ? n - base : chunk );
+        uint32_t cnt = ( uint32_t )( ( n_slots - base < chunk ) ? n_slots - base : chunk );
         int overflow = 0;
         uint32_t fullest = 0;
-        st = render_chunk( h, d_pos_xy, first, ( uint32_t )base, cnt, stream, &overflow, &fullest );
+        st = render_chunk( h, d_pos_xy, first, ( uint32_t )base, cnt, order, stream, &overflow, &fullest );
         if( st != ACN_OK ) return st;
         if( overflow )
         {
@@ -1025,7 +1048,8 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
             h->retries++;
             chunk = cnt / 2;
             h->recs_per_pos = cap / ( double )chunk;
-            HIP_TRY( hipMemsetAsync( h->d_accum + 3 * base, 0, sizeof( unsigned long long ) * 3 * cnt, stream ) );
+            hipLaunchKernelGGL( k_clear_slots, dim3( ( cnt + 255 ) / 256 ), dim3( 256 ), 0, stream, h->d_accum, ( uint32_t )base, cnt, order );
+            HIP_TRY( hipGetLastError() );
             continue;
         }
         h->chunks++;
@@ -1034,6 +1058,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
         {
             /* (small chunks over-estimate: the dead slots at the ends of the waves' queue reservations do not scale) */
             double per_pos = ( double )fullest / ( double )cnt;
+            if( per_pos < 0.9 * h->recs_per_pos ) per_pos = 0.9 * h->recs_per_pos;   /* forget slowly */
             if( per_pos < 1e-3 ) per_pos = 1e-3;
             h->recs_per_pos = per_pos;
             double next = 0.7 * cap / per_pos;

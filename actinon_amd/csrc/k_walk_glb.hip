@@ -3,7 +3,7 @@
 #include "acn_launch.h"
 
 void acn_launch_walk_glb( KernelFlags f, uint32_t pass, bool last, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
-                          const double* pos_xy, size_t first_pixel, uint32_t base, uint32_t n_cam,
+                          const double* pos_xy, size_t first_pixel, uint32_t base, uint32_t n_cam, TileOrder order,
                           unsigned long long* accum, unsigned long long* counters )
 {
     if( f.prune ) ACN_LW_( false, false, true );
