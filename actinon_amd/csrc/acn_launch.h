@@ -35,6 +35,7 @@ struct LevelQ
     unsigned grid;                                          /* workgroups of the persistent kernels */
     unsigned shade_grid;                                    /* workgroups of k_shade */
     uint32_t fetch_walk, fetch_hard;                        /* input items a wave reserves per cursor atomic */
+    uint32_t fetch_shade;                                   /* k_shade: steps of 64 / LPT tasks a wave reserves per atomic */
     uint32_t private_limit;                                 /* generations of at most this many rays are finished on private stacks */
 };
 
@@ -77,6 +78,6 @@ void NAME( KernelFlags f, const LevelQ& q, hipStream_t stream, const SceneArgs& 
     else               { if( f.leaf_lights ) ACN_LS_( LPT, CLS, false, true, false ); else ACN_LS_( LPT, CLS, false, false, false ); } \
 }
 #define ACN_LS_( LPT, CLS, C, L, P ) hipLaunchKernelGGL( ( k_shade< LPT, C, L, P > ), dim3( q.shade_grid ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS_OF( s ), \
-    ( const DTask* )q.tasks, ( const uint32_t* )q.idx[ CLS ], CLS, q.task_cap, q.children, q.child_cap, q.hard_shadow, q.hard_path, q.hard_cap, q.counts, accum, counters )
+    ( const DTask* )q.tasks, ( const uint32_t* )q.idx[ CLS ], CLS, q.task_cap, q.fetch_shade * ( 64u / LPT ), q.children, q.child_cap, q.hard_shadow, q.hard_path, q.hard_cap, q.counts, accum, counters )
 
 #endif

@@ -161,7 +161,7 @@ struct HardPath
 enum
 {
     QC_TASKS = 0, QC_CLASS0 = 1, QC_CHILDREN = 5, QC_FLAGS = 6, QC_HARD_SHADOW = 7, QC_HARD_PATH = 8,
-    QC_CUR_HS = 9, QC_CUR_HP = 10, QC_CUR_HITS = 11,
+    QC_CUR_HS = 9, QC_CUR_HP = 10, QC_CUR_HITS = 11, QC_CUR_SHADE0 = 20,   /* .. QC_CUR_SHADE0 + 3: one per size class */
     QS_WALK_RAYS = 12, QS_HARD_SHADOW = 13, QS_HARD_PATH = 14, QS_CHILDREN = 15, QS_TASKS = 16, QS_WALK_STEPS = 17, QS_PRIVATE_RAYS = 18,
     QC_GEN = 32, QC_CUR_GEN = QC_GEN + ACN_MAX_WALK_PASSES + 1,
     QC_N = 104
@@ -749,11 +749,11 @@ template< int LPT > DEV uint64_t lcg_stride( uint64_t x )   /* jump by 2*LPT dra
 
 /* LEAF_LIGHTS: every light is a plane / sphere / squaroid-free leaf, so the kernel contains no call into the CSG
  * machine at all (the usual case); otherwise the light hit goes through the generic element test.
- * The tasks are idx[ 0 .. min( p_counts[ QC_CLASS0 + cls ], task_cap ) ) (dead entries skipped), dealt to the waves
- * of the grid in strides. */
+ * The tasks are idx[ 0 .. min( p_counts[ QC_CLASS0 + cls ], task_cap ) ) (dead entries skipped); the persistent waves of
+ * the grid fetch them through the cursor of the class. */
 template< int LPT, bool COUNT, bool LEAF_LIGHTS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_SHADE_WAVES )
-void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t* __restrict__ idx, int cls, uint32_t task_cap,
+void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t* __restrict__ idx, int cls, uint32_t task_cap, uint32_t fetch_batch,
               HitRec* __restrict__ p_children, uint32_t child_cap, HardShadow* __restrict__ p_hard_shadow,
               HardPath* __restrict__ p_hard_path, uint32_t hard_cap, uint32_t* __restrict__ p_counts,
               unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
@@ -767,8 +767,6 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPT;
     const int grp = lane / LPT;
-    const uint32_t wave = ( blockIdx.x * blockDim.x + threadIdx.x ) >> 6;
-    const uint32_t n_waves = ( gridDim.x * blockDim.x ) >> 6;
     Cnt< COUNT > cnt;
     cnt.clear();
     const V3 bg = ld3( sc.prm.background_color );
@@ -780,10 +778,16 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
     auto kill_hp = [ p_hard_path ]( uint32_t k ) { p_hard_path[ k ].pixel = ACN_INVALID; };
     auto kill_ch = [ p_children ]( uint32_t k ) { p_children[ k ].pixel = ACN_INVALID; };
 
-    for( uint32_t base = wave * G; base < n_tasks; base += n_waves * G )
+    /* persistent waves: G tasks per step, fetched fetch_batch at a time through the class's cursor */
+    FetchRange fr;
+    fr.cur = fr.end = 0; fr.more = n_tasks > 0;
+    for( ;; )
     {
+        uint32_t base = 0;
+        uint32_t got = range_take( fr, p_counts + QC_CUR_SHADE0 + cls, fetch_batch, n_tasks, ( uint32_t )G, &base );
+        if( got == 0 ) break;
         uint32_t ti = base + grp;
-        if( ti >= n_tasks ) continue;
+        if( ( uint32_t )grp >= got ) continue;
         uint32_t slot = ( ( ElemP )( const void* )idx )[ ti ];
         if( LPT == 64 ) slot = __builtin_amdgcn_readfirstlane( slot );
         if( slot == ACN_INVALID ) continue;

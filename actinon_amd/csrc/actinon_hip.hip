@@ -71,15 +71,16 @@ struct LaneWorker
  * host that changes its environment, and would let a value change between the concurrent lanes of one call) */
 struct Tunables
 {
-    size_t   workspace_mb = 16384;     /* ACN_WORKSPACE_MB: upper bound of the queue workspace of one handle (all its lanes) */
+    size_t   workspace_mb = 32768;     /* ACN_WORKSPACE_MB: upper bound of the queue workspace of one handle (all its lanes) */
     size_t   chunk = 0;                /* ACN_CHUNK: sample positions per pipeline run, 0 = derived from the queue capacity */
-    int      lanes = 2;                /* ACN_LANES: concurrent pipeline runs of a large call */
+    int      lanes = 4;                /* ACN_LANES: concurrent pipeline runs of a large call */
     unsigned grid = 0;                 /* ACN_GRID: workgroups of the persistent kernels, 0 = 4 per compute unit */
     unsigned shade_grid = 0;           /* ACN_SHADE_GRID: workgroups of k_shade, 0 = 4 per compute unit */
     uint32_t stack_cap = 512;          /* ACN_STACK_CAP: private ray slots per k_walk wave */
     uint32_t fetch_walk = 64;          /* ACN_FETCH_WALK: fresh rays a k_walk wave reserves per cursor atomic */
     uint32_t walk_passes = 12;         /* ACN_WALK_PASSES: launches of k_walk per path level (the last one finishes whatever is left) */
     uint32_t private_limit = 32768;    /* ACN_PRIVATE_LIMIT: a generation of at most this many rays is finished on private stacks */
+    uint32_t fetch_shade = 2;          /* ACN_FETCH_SHADE: steps ( of 64 / lanes-per-task tasks ) a k_shade wave reserves per cursor atomic */
     uint32_t fetch_hard = 256;         /* ACN_FETCH_HARD: records a wave of the hard-ray kernels / k_shade_hits reserves per atomic */
     uint32_t stack_use = 0;            /* ACN_TEST_STACK_USE: slots of a private stack every walk pass but the last uses (tests of the overflow path) */
     bool     count_work = false;       /* ACN_COUNT_WORK */
@@ -95,6 +96,8 @@ struct Tunables
         if( const char* e = getenv( "ACN_TEST_STACK_USE" ) ) stack_use = ( uint32_t )atoll( e );
         if( const char* e = getenv( "ACN_FETCH_WALK" ) ) fetch_walk = ( uint32_t )atoll( e );
         if( const char* e = getenv( "ACN_FETCH_HARD" ) ) fetch_hard = ( uint32_t )atoll( e );
+        if( const char* e = getenv( "ACN_FETCH_SHADE" ) ) fetch_shade = ( uint32_t )atoll( e );
+        if( fetch_shade < 1 ) fetch_shade = 1;
         if( const char* e = getenv( "ACN_WALK_PASSES" ) ) walk_passes = ( uint32_t )atoll( e );
         if( const char* e = getenv( "ACN_PRIVATE_LIMIT" ) ) private_limit = ( uint32_t )atoll( e );
         if( walk_passes < 1 ) walk_passes = 1;
@@ -805,7 +808,7 @@ static size_t bytes_per_record()
 
 /* Queue capacities.  Only one chunk of positions is in flight per pipeline run, so the queues are sized for a chunk,
  * not for the call: room for the path-sample hits of ACN_CHUNK_TARGET positions (or of the whole call if it is smaller)
- * over two path levels, bounded by the handle's budget (ACN_WORKSPACE_MB, default 16 GiB, shared by its
+ * over two path levels, bounded by the handle's budget (ACN_WORKSPACE_MB, default 32 GiB, shared by its
  * lanes).  If the device cannot give that much, the request is halved until it fits: the chunk size follows the
  * capacity (launch_render), so a small workspace costs more chunks, not correctness. */
 #define ACN_CHUNK_TARGET ( ( size_t )1 << 18 )
@@ -898,7 +901,7 @@ static LevelQ level_queues( const acn_scene_handle* h, int level )
     q.counts = h->d_counts + ( size_t )level * QC_N;
     q.prev_children = h->d_counts + ( size_t )( level > 0 ? level - 1 : 0 ) * QC_N + QC_CHILDREN;
     q.grid = h->grid; q.shade_grid = h->shade_grid;
-    q.fetch_walk = h->tun.fetch_walk; q.fetch_hard = h->tun.fetch_hard; q.private_limit = h->tun.private_limit;
+    q.fetch_walk = h->tun.fetch_walk; q.fetch_hard = h->tun.fetch_hard; q.private_limit = h->tun.private_limit; q.fetch_shade = h->tun.fetch_shade;
     return q;
 }
 static size_t machine_lds_bytes( const acn_scene_handle* h ) { return h->lds_bytes + h->lds_stack_bytes; }

@@ -13,6 +13,9 @@
 
 int main( int argc, const char** argv )
 {
+    /* the library's concurrent lanes want their streams on distinct hardware queues (ROCm maps streams onto
+     * GPU_MAX_HW_QUEUES queues, default 4); set here, in the program, before anything initialises HIP */
+    setenv( "GPU_MAX_HW_QUEUES", "8", 0 );
     printf( "ACTINON-HIP: ray tracer, MI355X render path.\n\n" );
     if( argc < 2 )
     {
