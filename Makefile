@@ -33,10 +33,10 @@ actinon_amd/bin/actinon_hip: tools/actinon_hip.c include/acn_interp.h $(LIBDIR)/
 	@mkdir -p actinon_amd/bin
 	$(CC) $(CFLAGS) -o $@ tools/actinon_hip.c -L$(LIBDIR) -lactinon_host -lactinon_hip -lm -Wl,-rpath,'$$ORIGIN/../lib'
 
-oracle/libacn_oracle.so: oracle/acn_oracle.c oracle/acn_oracle.h actinon_amd/csrc/acn_detmath.h include/actinon_hip.h
+oracle/libacn_oracle.so: oracle/acn_oracle.c oracle/acn_oracle.h actinon_amd/csrc/acn_detmath.h actinon_amd/csrc/acn_costs.h include/actinon_hip.h
 	$(CC) $(CFLAGS) -march=native -Ioracle -shared -o $@ oracle/acn_oracle.c -lm -lpthread
 
-oracle/libacn_oracle_libm.so: oracle/acn_oracle.c oracle/acn_oracle.h include/actinon_hip.h
+oracle/libacn_oracle_libm.so: oracle/acn_oracle.c oracle/acn_oracle.h actinon_amd/csrc/acn_costs.h include/actinon_hip.h
 	$(CC) $(CFLAGS) -march=native -DACN_ORACLE_LIBM -Ioracle -shared -o $@ oracle/acn_oracle.c -lm -lpthread
 
 clean:

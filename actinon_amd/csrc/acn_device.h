@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include "actinon_hip.h"
 #include "acn_detmath.h"
+#include "acn_costs.h"
 
 #pragma clang fp contract(off)
 
@@ -170,16 +171,24 @@ template< bool ON > struct Cnt;
 template<> struct Cnt< true >
 {
     unsigned c[ CNT_N ];
-    __device__ __forceinline__ void clear() { for( int k = 0; k < CNT_N; k++ ) c[ k ] = 0; }
+    unsigned long long flop;   /* sum of event costs, acn_costs.h */
+    unsigned transc;           /* transcendental calls */
+    __device__ __forceinline__ void clear() { for( int k = 0; k < CNT_N; k++ ) c[ k ] = 0; flop = 0; transc = 0; }
     __device__ __forceinline__ void inc( int k ) { c[ k ]++; }
     __device__ __forceinline__ void add( int k, unsigned v ) { c[ k ] += v; }
+    __device__ __forceinline__ void cost( unsigned f, unsigned t = 0 ) { flop += f; transc += t; }
 };
 template<> struct Cnt< false >
 {
     __device__ __forceinline__ void clear() {}
     __device__ __forceinline__ void inc( int ) {}
     __device__ __forceinline__ void add( int, unsigned ) {}
+    __device__ __forceinline__ void cost( unsigned, unsigned = 0 ) {}
 };
+/* the leaf routines below take the lane's counters as their last argument; call sites are written without it and the
+ * macros behind each definition append the `cnt` of the calling function (our own pruning tests, which are not events
+ * of the reference's algorithm, call the underscore forms with ACN_NO_CNT) */
+#define ACN_NO_CNT ( ( Cnt< false >* )nullptr )
 
 /* the two read-only scene arrays, passed BY VALUE into the non-inlined machines (global address space, so the
  * scene struct is never forced into scratch) */
@@ -341,22 +350,24 @@ DEV V3 v_random_sphere_belt( uint64_t* rv, double h )   /* vectors.h:209-218 */
 }
 
 /* ---- gmath.h:38-97 ---- */
-DEV double plane_ray_hit( V3 pos, V3 nor, V3 rp, V3 rd, bool want_nor, V3* p_nor )
+template< class CT > DEV double plane_ray_hit_( V3 pos, V3 nor, V3 rp, V3 rd, bool want_nor, V3* p_nor, CT* cnt )
 {
+    cnt->cost( ACN_F_PLANE_HIT );
     double div = v_mlv( nor, rd );
     if( div == 0 ) return F3_INF;
     double offs = v_sub_mlv( pos, rp, nor ) / div;
     if( want_nor ) *p_nor = nor;
     return ( offs > 0 ) ? offs - F3_EPS : F3_INF;
 }
+#define plane_ray_hit( ... ) plane_ray_hit_( __VA_ARGS__, cnt )
 
-DEV double sphere_ray_hit( V3 pos, double r, V3 rp, V3 rd, bool want_nor, V3* p_nor )
+template< class CT > DEV double sphere_ray_hit_( V3 pos, double r, V3 rp, V3 rd, bool want_nor, V3* p_nor, CT* cnt )
 {
     V3 p = v_sub( rp, pos );
     double s = v_mlv( p, rd );
     double q = v_sqr( p ) - ( r * r );
     double s2 = s * s;
-    if( s2 < q ) return F3_INF;
+    if( s2 < q ) { cnt->cost( ACN_F_SPHERE_MISS ); return F3_INF; }
     double offs = F3_INF;
     if( s < 0 && q > 0 )
     {
@@ -367,14 +378,18 @@ DEV double sphere_ray_hit( V3 pos, double r, V3 rp, V3 rd, bool want_nor, V3* p_
         offs = -s + acn_sqrt( s2 - q ) - F3_EPS;
     }
     if( offs < F3_INF && want_nor ) *p_nor = v_of_length( v_sub( ray_pos( rp, rd, offs ), pos ), 1.0 );
+    cnt->cost( offs < F3_INF ? ( want_nor ? ACN_F_SPHERE_HIT_NOR : ACN_F_SPHERE_HIT ) : ACN_F_SPHERE_MISS );
     return offs;
 }
+#define sphere_ray_hit( ... ) sphere_ray_hit_( __VA_ARGS__, cnt )
 
-DEV int sphere_observer_side( V3 pos, double r, V3 observer )
+template< class CT > DEV int sphere_observer_side_( V3 pos, double r, V3 observer, CT* cnt )
 {
+    cnt->cost( ACN_F_SIDE_SPHERE );
     V3 diff = v_sub( observer, pos );
     return ( v_sqr( diff ) > r * r ) ? 1 : -1;
 }
+#define sphere_observer_side( ... ) sphere_observer_side_( __VA_ARGS__, cnt )
 
 /* ---- gmath.c:68-113 ---- */
 DEV double fresnel_reflection( V3 dir_i, V3 exit_nor, double trix, V3* dir )
@@ -422,23 +437,27 @@ template< class NP > DEV M3 node_rax( NP n )
 /* envelope_s_ray_hits (objects.c:90-93) = sphere_ray_hit( ... ) < f3_inf.  Only the predicate is needed: by
  * gmath.h:64-83 the offset is finite exactly when s*s >= q and ( s < 0 or q < 0 ) -- the square root of the
  * non-negative discriminant is finite for finite inputs -- so the sqrt is not evaluated. */
-template< class NP > DEV bool env_ray_hits( NP n, V3 rp, V3 rd )
+template< class NP, class CT > DEV bool env_ray_hits_( NP n, V3 rp, V3 rd, CT* cnt )
 {
     V3 p = v_sub( rp, ld3( n->env_pos ) );
     double r = n->env_radius;
     double s = v_mlv( p, rd );
     double q = v_sqr( p ) - ( r * r );
     double s2 = s * s;
-    if( s2 < q ) return false;
-    return ( s < 0 && q > 0 ) || ( s < 0 || q < 0 );
+    bool hit = !( s2 < q ) && ( ( s < 0 && q > 0 ) || ( s < 0 || q < 0 ) );
+    cnt->cost( hit ? ACN_F_ENV_HIT : ACN_F_ENV_MISS );
+    return hit;
 }
-template< class NP > DEV int env_side( NP n, V3 pos ) { return sphere_observer_side( ld3( n->env_pos ), n->env_radius, pos ); }
+#define env_ray_hits( ... ) env_ray_hits_( __VA_ARGS__, cnt )
+template< class NP, class CT > DEV int env_side_( NP n, V3 pos, CT* cnt ) { return sphere_observer_side_( ld3( n->env_pos ), n->env_radius, pos, cnt ); }
+#define env_side( ... ) env_side_( __VA_ARGS__, cnt )
 
 /* ---- distance.c:39-42, 83-92 ---- */
-template< class NP > DEV double sdf_eval( NP n, V3 pos )
+template< class NP, class CT > DEV double sdf_eval_( NP n, V3 pos, CT* cnt )
 {
     if( n->sdf_kind == ACN_SDF_TORUS )
     {
+        cnt->cost( ACN_F_SDF_TORUS );
         double x = pos.x;
         double y = pos.y;
         double f = acn_sqrt( x * x + y * y );
@@ -447,12 +466,15 @@ template< class NP > DEV double sdf_eval( NP n, V3 pos )
         y *= f_inv;
         return acn_sqrt( f_sqr( x - pos.x ) + f_sqr( y - pos.y ) + f_sqr( pos.z ) ) - n->prm[ 1 ];
     }
+    cnt->cost( ACN_F_SDF_SPHERE );
     return acn_sqrt( f_sqr( pos.x ) + f_sqr( pos.y ) + f_sqr( pos.z ) ) - 1.0;
 }
+#define sdf_eval( ... ) sdf_eval_( __VA_ARGS__, cnt )
 
 /* ---- leaves ---- */
-template< class NP > DEV double squaroid_ray_hit( NP o, V3 rp, V3 rd, bool want_nor, V3* p_nor )   /* objects.c:778-821 */
+template< class NP, class CT > DEV double squaroid_ray_hit_( NP o, V3 rp, V3 rd, bool want_nor, V3* p_nor, CT* cnt )   /* objects.c:778-821 */
 {
+    cnt->cost( ACN_F_SQUAROID_MISS );
     M3 rax = node_rax( o );
     double oa = o->prm[ 0 ], ob = o->prm[ 1 ], oc = o->prm[ 2 ], orr = o->prm[ 3 ];
     V3 p = m_mlv( rax, v_sub( rp, ld3( o->pos ) ) );
@@ -478,6 +500,7 @@ template< class NP > DEV double squaroid_ray_hit( NP o, V3 rp, V3 rd, bool want_
         a = ( fq != 0 ) ? -fs / ( 2 * fq ) : F3_INF;
     }
     if( a == F3_INF ) return F3_INF;
+    cnt->cost( ( want_nor ? ACN_F_SQUAROID_HIT_NOR : ACN_F_SQUAROID_HIT ) - ACN_F_SQUAROID_MISS );
     if( want_nor )
     {
         double x = p.x + a * d.x;
@@ -488,13 +511,16 @@ template< class NP > DEV double squaroid_ray_hit( NP o, V3 rp, V3 rd, bool want_
     }
     return a - F3_EPS;
 }
+#define squaroid_ray_hit( ... ) squaroid_ray_hit_( __VA_ARGS__, cnt )
 
-template< class NP > DEV int squaroid_side( NP o, V3 pos )   /* objects.c:823-827 */
+template< class NP, class CT > DEV int squaroid_side_( NP o, V3 pos, CT* cnt )   /* objects.c:823-827 */
 {
+    cnt->cost( ACN_F_SIDE_SQUAROID );
     M3 rax = node_rax( o );
     V3 p = m_mlv( rax, v_sub( pos, ld3( o->pos ) ) );
     return ( o->prm[ 0 ] * p.x * p.x + o->prm[ 1 ] * p.y * p.y + o->prm[ 2 ] * p.z * p.z + o->prm[ 3 ] ) > 0 ? 1 : -1;
 }
+#define squaroid_side( ... ) squaroid_side_( __VA_ARGS__, cnt )
 
 template< class NP, class CT >
 DEVN double distance_ray_hit( NP o, V3 rp, V3 rd, bool want_nor, V3* p_nor, CT* cnt )   /* objects.c:903-959 */
@@ -540,10 +566,12 @@ DEVN double distance_ray_hit( NP o, V3 rp, V3 rd, bool want_nor, V3* p_nor, CT* 
         }
     }
     cnt->add( CNT_SDF_EVAL, evals );
+    cnt->cost( ACN_F_SDF_RAY + ACN_F_SDF_STEP * ( evals - 1 ) );
     if( f_abs( dist ) <= F3_EPS )
     {
         if( want_nor )
         {
+            cnt->cost( ACN_F_SDF_NORMAL );
             V3 q = ray_pos( p, d, offs1 );
             double d0 = sdf_eval( o, q );
             V3 n;
@@ -557,16 +585,19 @@ DEVN double distance_ray_hit( NP o, V3 rp, V3 rd, bool want_nor, V3* p_nor, CT* 
     return F3_INF;
 }
 
-template< class NP > DEV int distance_side( NP o, V3 pos )   /* objects.c:961-966 */
+template< class NP, class CT > DEV int distance_side_( NP o, V3 pos, CT* cnt )   /* objects.c:961-966 */
 {
+    cnt->cost( ACN_F_SIDE_SDF );
     if( node_has_env( o ) && env_side( o, pos ) == 1 ) return 1;
     M3 rax = node_rax( o );
     V3 p = v_mlf( m_mlv( rax, v_sub( pos, ld3( o->pos ) ) ), o->prm[ 0 ] );
     return sdf_eval( o, p ) > 0 ? 1 : -1;
 }
+#define distance_side( ... ) distance_side_( __VA_ARGS__, cnt )
 
-template< class NP > DEV V3 roughness_normal( NP hdr, V3 n, V3 hit_pos )   /* objects.c:267-282 */
+template< class NP, class CT > DEV V3 roughness_normal_( NP hdr, V3 n, V3 hit_pos, CT* cnt )   /* objects.c:267-282 */
 {
+    cnt->cost( ACN_F_ROUGHNESS, ACN_T_ROUGHNESS );
     uint64_t rv = v_random_seed( hit_pos, 1246 );
     double f;
     f = f3_rnd0( &rv ) * 0.99;
@@ -577,6 +608,7 @@ template< class NP > DEV V3 roughness_normal( NP hdr, V3 n, V3 hit_pos )   /* ob
     n.z += hdr->surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
     return v_of_length( n, 1.0 );
 }
+#define roughness_normal( ... ) roughness_normal_( __VA_ARGS__, cnt )
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* Leaf pairs.  Most composites at the bottom of a CSG tree combine two simple operands -- a plane, sphere or squaroid,
@@ -587,13 +619,14 @@ template< class NP > DEV V3 roughness_normal( NP hdr, V3 n, V3 hit_pos )   /* ob
 #define ACN_GFLAG_LEAF_PAIR 0x100u      /* device-only bits of GNode.flags: a level-1 pair ... */
 #define ACN_GFLAG_PAIR2     0x400u      /* ... a level-2 pair: at least one operand is a level-1 pair (machines only) */
 
-template< class NP > DEV int simple_leaf_side( NP g, V3 pos )
+template< class NP, class CT > DEV int simple_leaf_side_( NP g, V3 pos, CT* cnt )
 {
     int type = g->type;
-    if( type == ACN_PLANE )  return v_sub_mlv( pos, ld3( g->pos ), ld3( g->rax + 6 ) ) > 0 ? 1 : -1;
+    if( type == ACN_PLANE )  { cnt->cost( ACN_F_SIDE_PLANE ); return v_sub_mlv( pos, ld3( g->pos ), ld3( g->rax + 6 ) ) > 0 ? 1 : -1; }
     if( type == ACN_SPHERE ) return sphere_observer_side( ld3( g->pos ), g->prm[ 0 ], pos );
     return squaroid_side( g, pos );
 }
+#define simple_leaf_side( ... ) simple_leaf_side_( __VA_ARGS__, cnt )
 
 /* Pairs of level L: both operands are a simple leaf, NEG( simple leaf ) or -- for L = 2 -- a level-1 pair.  The
  * functions below are the reference's obj_side / obj_ray_hit for such operands and pairs, recursion unrolled by L.
@@ -614,7 +647,7 @@ template< int L, class SR, class CT > DEV int operand_side( SR sc, int c, V3 pos
     return -r;
 }
 
-template< class NP > DEV double simple_leaf_hit( NP g, V3 rp, V3 rd, bool want_nor, V3* nor )
+template< class NP, class CT > DEV double simple_leaf_hit_( NP g, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
 {
     int type = g->type;
     double a;
@@ -624,6 +657,7 @@ template< class NP > DEV double simple_leaf_hit( NP g, V3 rp, V3 rd, bool want_n
     if( want_nor && a < F3_INF && g->surface_roughness > 0 ) *nor = roughness_normal( g, *nor, ray_pos( rp, rd, a ) );
     return a;
 }
+#define simple_leaf_hit( ... ) simple_leaf_hit_( __VA_ARGS__, cnt )
 
 template< int L, class SR, class CT > DEV double operand_hit( SR sc, int c, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
 {
@@ -666,8 +700,10 @@ template< int L, class SR, class NP, class CT > DEV double pair_hit( SR sc, NP n
     V3 n1 = mk( 0, 0, 0 ), n2 = mk( 0, 0, 0 );
     double a1 = operand_hit< L >( sc, c0, rp, rd, want_nor, &n1, cnt );
     double a2 = operand_hit< L >( sc, c1, rp, rd, want_nor, &n2, cnt );
+    cnt->cost( ACN_F_PAIR_STEP );
     if( a1 < a2 && operand_side< L >( sc, c1, ray_pos( rp, rd, a1 ), cnt ) == want ) { *nor = n1; return a1; }
     if( a2 >= F3_INF ) return F3_INF;
+    cnt->cost( ACN_F_PAIR_STEP );
     if( operand_side< L >( sc, c0, ray_pos( rp, rd, a2 ), cnt ) == want ) { *nor = n2; return a2; }
     double offs = a2;
     bool swapped = false;
@@ -675,6 +711,7 @@ template< int L, class SR, class NP, class CT > DEV double pair_hit( SR sc, NP n
     {
         V3 walk_p = ray_pos( rp, rd, offs );
         double a = operand_hit< L >( sc, swapped ? c1 : c0, walk_p, rd, want_nor, &n1, cnt );
+        cnt->cost( ACN_F_PAIR_STEP );
         if( a >= F3_INF ) return F3_INF;
         if( operand_side< L >( sc, swapped ? c0 : c1, ray_pos( walk_p, rd, a ), cnt ) == want ) { *nor = n1; return offs + a; }
         offs += a + 2 * F3_EPS;
@@ -728,7 +765,7 @@ DEV_SIDE int obj_side_dev( SR sc, int root, V3 pos, CT* cnt )
         {
             switch( type )
             {
-                case ACN_PLANE:    r = v_sub_mlv( pos, ld3( n->pos ), ld3( n->rax + 6 ) ) > 0 ? 1 : -1; break;   /* gmath.h:52-55 */
+                case ACN_PLANE:    cnt->cost( ACN_F_SIDE_PLANE ); r = v_sub_mlv( pos, ld3( n->pos ), ld3( n->rax + 6 ) ) > 0 ? 1 : -1; break;   /* gmath.h:52-55 */
                 case ACN_SPHERE:   r = sphere_observer_side( ld3( n->pos ), n->prm[ 0 ], pos ); break;
                 case ACN_SQUAROID: r = squaroid_side( n, pos ); break;
                 default:           r = distance_side( n, pos ); cnt->inc( CNT_SDF_EVAL ); break;
@@ -757,6 +794,7 @@ DEV_SIDE int obj_side_dev( SR sc, int root, V3 pos, CT* cnt )
             cur = ACN_PACK_SIDE( node, 1 );
             if( type == ACN_SCALE )   /* objects.c:1439-1443 */
             {
+                cnt->cost( ACN_F_SIDE_SCALE );
                 aux[ na++ ] = pos;    /* na <= depth <= ACN_CSG_MAX_DEPTH */
                 M3 rax = node_rax( n );
                 V3 p = m_mlv( rax, v_sub( pos, ld3( n->pos ) ) );
@@ -882,6 +920,7 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
             rp_derived = false;
             if( type == ACN_SCALE )   /* objects.c:1418-1428 */
             {
+                cnt->cost( ACN_F_SCALE_WRAP );
                 M3 rax = node_rax( n );
                 V3 inv_scale = mk( n->prm[ 0 ], n->prm[ 1 ], n->prm[ 2 ] );
                 V3 p2 = v_mld( m_mlv( rax, v_sub( rp, ld3( n->pos ) ) ), inv_scale );
@@ -945,6 +984,7 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
                 }
                 else if( pc == 2 )
                 {
+                    cnt->cost( 2 * ACN_F_PAIR_STEP );
                     double a1 = cur_a, a2 = ret_a;
                     if( a1 < a2 && obj_side_dev( sc, fn->child1, ray_pos( cur_rp, rd, a1 ), cnt ) == want )
                     {
@@ -968,6 +1008,7 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
                 }
                 else
                 {
+                    cnt->cost( ACN_F_PAIR_STEP );
                     double a = ret_a;
                     if( a >= F3_INF )
                     {
@@ -1130,7 +1171,7 @@ template< int D, class SC >
 DEV bool surely_outside( const SC& sc, int node, V3 rp, V3 rd )
 {
     auto n = &sc.nodes[ node ];
-    if( node_has_env( n ) && !env_ray_hits( n, rp, rd ) ) return true;
+    if( node_has_env( n ) && !env_ray_hits_( n, rp, rd, ACN_NO_CNT ) ) return true;
     if constexpr( D > 0 )
     {
         int type = n->type;
@@ -1294,7 +1335,7 @@ DEV bool prune_exec( NP nodes, ElemP elems, int pc, V3 rp, V3 rd, double limit )
         }
         else if( op == ACN_PO_ENV )
         {
-            if( !env_ray_hits( n, rp, rd ) ) { h0 = iv_none(); s0 = iv_none(); }   /* the machine's own test (objects.c:264) */
+            if( !env_ray_hits_( n, rp, rd, ACN_NO_CNT ) ) { h0 = iv_none(); s0 = iv_none(); }   /* the machine's own test (objects.c:264) */
             else s0 = iv_and( s0, iv_ball( ld3( n->env_pos ), n->env_radius, rp, rd ) );
         }
         else
@@ -1402,6 +1443,7 @@ DEV double root_trans_hit( const SC& sc, int cmp, V3 rp, V3 rd, Trans* trans, CT
         double a = element_hit< true >( sc, element, rp, rd, &nor, &hit_obj, -F3_INF, cnt );
         if( a < F3_INF )
         {
+            cnt->cost( ACN_F_TRANS_RESOLVE );
             if( a < min_a - F3_EPS )
             {
                 min_a = a;
@@ -1491,7 +1533,7 @@ DEV int root_occluded_fast( const SC& sc, int cmp, V3 rp, V3 rd, double limit, C
             double a = simple_compound_hit< false >( sc, element, rp, rd, nullptr, &ho, limit, cnt );
             if( a <= limit ) return 1;
         }
-        else if( type == ACN_COMPOUND || type == ACN_DISTANCE ? ( !node_has_env( n ) || env_ray_hits( n, rp, rd ) )
+        else if( type == ACN_COMPOUND || type == ACN_DISTANCE ? ( !node_has_env( n ) || env_ray_hits_( n, rp, rd, ACN_NO_CNT ) )
                                                               : !( surely_outside< ACN_PRUNE_DEPTH >( sc, element, rp, rd ) || ACN_FAST_PRUNE( sc, element, rp, rd, limit ) ) )
         {
             hard = true;
@@ -1517,7 +1559,7 @@ DEV double root_trans_hit_fast( const SC& sc, int cmp, V3 rp, V3 rd, Trans* tran
         int type = n->type;
         if( !is_fast_type( type ) && !( n->flags & ( ACN_GFLAG_LEAF_PAIR | ( SC::prune ? ACN_GFLAG_SIMPLE_COMPOUND : 0u ) ) ) )
         {
-            if( type == ACN_COMPOUND || type == ACN_DISTANCE ? ( !node_has_env( n ) || env_ray_hits( n, rp, rd ) )
+            if( type == ACN_COMPOUND || type == ACN_DISTANCE ? ( !node_has_env( n ) || env_ray_hits_( n, rp, rd, ACN_NO_CNT ) )
                                                              : !( surely_outside< ACN_PRUNE_DEPTH >( sc, element, rp, rd ) || ACN_FAST_PRUNE( sc, element, rp, rd, F3_INF ) ) ) h = true;
             continue;
         }
@@ -1536,6 +1578,7 @@ DEV double root_trans_hit_fast( const SC& sc, int cmp, V3 rp, V3 rd, Trans* tran
         }
         if( a < F3_INF )
         {
+            cnt->cost( ACN_F_TRANS_RESOLVE );
             if( a < min_a - F3_EPS )
             {
                 min_a = a;

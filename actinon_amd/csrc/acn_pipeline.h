@@ -263,17 +263,30 @@ DEV uint32_t wave_fetch( uint32_t* cursor, uint32_t want, uint32_t n, uint32_t* 
     return n - b < want ? n - b : want;
 }
 
-/* the same in batches: the wave owns the range [ cur, end ) of the input and refills it with ONE atomic per `batch`
- * items (all three are the same in every lane) */
-struct FetchRange { uint32_t cur, end; bool more; };
+/* the same in batches, one ahead: the wave owns the range [ cur, end ) of the input and, while it works that off, the
+ * atomic that reserves its next batch is already in flight -- its 1-2 us round trip overlaps the work instead of
+ * stalling the wave once per batch.  ( cur, end, more are the same in every lane; next is lane 0's. ) */
+struct FetchRange { uint32_t cur, end, next; bool pending, more; };
+DEV void range_init( FetchRange& r, bool any ) { r.cur = r.end = r.next = 0; r.pending = false; r.more = any; }
 DEV uint32_t range_take( FetchRange& r, uint32_t* cursor, uint32_t batch, uint32_t n, uint32_t want, uint32_t* first )
 {
     if( r.cur == r.end && r.more )
     {
-        uint32_t b = 0;
-        uint32_t got = wave_fetch( cursor, batch, n, &b );
-        r.cur = b; r.end = b + got;
-        if( b + batch >= n ) r.more = false;
+        if( !r.pending && ( threadIdx.x & 63 ) == 0 ) r.next = atomicAdd( cursor, batch );
+        uint32_t b = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )r.next );
+        r.pending = false;
+        if( b >= n ) { r.more = false; r.cur = r.end = 0; }
+        else
+        {
+            r.cur = b;
+            r.end = n - b < batch ? n : b + batch;
+            if( b + batch >= n ) r.more = false;
+            else
+            {
+                if( ( threadIdx.x & 63 ) == 0 ) r.next = atomicAdd( cursor, batch );   /* the batch after this one */
+                r.pending = true;
+            }
+        }
     }
     uint32_t have = r.end - r.cur;
     uint32_t take = have < want ? have : want;
@@ -363,7 +376,7 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
 {
     const double min_intensity = sc.prm.trace_min_intensity;
     bool go = !( depth == 0 || intensity < min_intensity );
-    if( go ) cnt->inc( CNT_LUM );
+    if( go ) { cnt->inc( CNT_LUM ); cnt->cost( ACN_F_LUM_FIXED ); }
     V3 pos = ray_pos( rp, rd, offs );
     MatP enter_obj = ( go && trans.enter_obj >= 0 ) ? &sc.mats[ trans.enter_obj ] : nullptr;
     MatP exit_obj  = ( go && trans.exit_obj  >= 0 ) ? &sc.mats[ trans.exit_obj  ] : nullptr;
@@ -374,6 +387,7 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
         double light_intensity = ( diff_sqr > 0 ) ? ( enter_obj->radiance / diff_sqr ) : F3_MAG;
         V3 c = v_mlf( obj_color_dev( sc, trans.enter_obj, pos ), light_intensity * intensity );
         acc.x += T.x * c.x; acc.y += T.y * c.y; acc.z += T.z * c.z;
+        cnt->cost( ACN_F_EMISSION );
         go = false;
     }
 
@@ -406,6 +420,7 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
         transparent = true;
         if( offs > 0 )
         {
+            cnt->cost( ACN_F_ABSORB, ACN_T_ABSORB );
             T.x *= acn_pow( exit_obj->transparency[ 0 ], offs );
             T.y *= acn_pow( exit_obj->transparency[ 1 ], offs );
             T.z *= acn_pow( exit_obj->transparency[ 2 ], offs );
@@ -417,7 +432,7 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
         bool f = go && fresnel_reflectivity > 0 && intensity >= min_intensity;
         V3 out_d = rd;
         double reflectance = 0;
-        if( f ) reflectance = fresnel_reflection( rd, trans.exit_nor, trix, &out_d ) * fresnel_reflectivity;
+        if( f ) { cnt->cost( ACN_F_FRESNEL_REFL ); reflectance = fresnel_reflection( rd, trans.exit_nor, trix, &out_d ) * fresnel_reflectivity; }
         rays.push( f, pos, out_d, T, reflectance * intensity, depth - 1, pixel );
         if( f ) intensity *= ( 1.0 - reflectance );
     }
@@ -426,7 +441,7 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
     {
         bool f = go && chromatic_reflectivity > 0 && intensity >= min_intensity;
         V3 out_d = rd;
-        if( f ) out_d = v_reflection( rd, trans.exit_nor );
+        if( f ) { cnt->cost( ACN_F_REFLECTION ); out_d = v_reflection( rd, trans.exit_nor ); }
         rays.push( f, pos, out_d, v_mld( T, enter_color ), chromatic_reflectivity * intensity, depth - 1, pixel );
         if( f ) intensity *= ( 1.0 - chromatic_reflectivity );
     }
@@ -437,6 +452,7 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
     uint64_t n_direct = 0, n_path = 0;
     if( diffuse )
     {
+        cnt->cost( ACN_F_SHADE_DIFFUSE + ACN_F_SEED, ACN_T_SHADE_DIFFUSE + ACN_T_SEED );
         if( sc.nodes[ sc.light_root ].child1 > 0 )
         {
             n_direct = ( uint64_t )( sc.prm.direct_samples * diffuse_intensity );
@@ -487,7 +503,7 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
     {
         bool f = go && transparent && intensity >= min_intensity;
         V3 out_d = rd;
-        if( f ) out_d = fresnel_refraction( rd, trans.exit_nor, trix );
+        if( f ) { cnt->cost( ACN_F_FRESNEL_REFR ); out_d = fresnel_refraction( rd, trans.exit_nor, trix ); }
         rays.push( f, ray_pos( rp, rd, offs + 2.0 * F3_EPS ), out_d, T, intensity, depth - 1, pixel );
     }
 }
@@ -504,9 +520,9 @@ DEV void task_chunks_close( const TaskQ& tq, ChunkP tcs )
 
 DEV void wave_add_counters( unsigned long long* global, const Cnt< true >& mine )
 {
-    for( int k = 0; k < CNT_N; k++ )
+    for( int k = 0; k < CNT_N + 2; k++ )
     {
-        unsigned long long v = mine.c[ k ];
+        unsigned long long v = k < CNT_N ? mine.c[ k ] : k == CNT_N ? mine.flop : mine.transc;   /* [ CNT_N ] flop, [ CNT_N + 1 ] transcendentals */
         for( int off = 32; off > 0; off >>= 1 ) v += __shfl_down( v, off, 64 );
         if( ( threadIdx.x & 63 ) == 0 && v ) atomicAdd( &global[ k ], v );
     }
@@ -610,7 +626,7 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
     sink.out.rays = rays_out; sink.out.counter = p_counts + QC_GEN + pass + 1; sink.out.cap = out_cap; sink.out.flags = p_counts + QC_FLAGS; sink.out.cs = cs + 5;
     uint32_t* cursor = p_counts + QC_CUR_GEN + pass;
     FetchRange fr;
-    fr.cur = fr.end = 0; fr.more = true;
+    range_init( fr, true );
     uint32_t traced = 0, steps = 0;
     bool finished = false;
     for( uint32_t step = 0; step < ACN_WALK_MAX_STEPS; step++ )
@@ -645,6 +661,7 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
                     my = ( double )( pix / sc.prm.image_width ) + 0.5;
                 }
                 camera_ray( sc, mx, my, &rp, &rd );
+                if( live ) cnt.cost( ACN_F_CAMERA_RAY );
             }
         }
         if( src && live ) { rp = src->p; rd = src->d; }
@@ -706,7 +723,7 @@ void k_shade_hits( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const HitRec* __restrict_
     RayQ rq;
     rq.rays = rays_out; rq.counter = p_counts + QC_GEN; rq.cap = ray_cap; rq.flags = p_counts + QC_FLAGS; rq.cs = cs + 5;
     FetchRange fr;
-    fr.cur = fr.end = 0; fr.more = n > 0;
+    range_init( fr, n > 0 );
     for( ;; )
     {
         uint32_t first = 0;
@@ -780,7 +797,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
 
     /* persistent waves: G tasks per step, fetched fetch_batch at a time through the class's cursor */
     FetchRange fr;
-    fr.cur = fr.end = 0; fr.more = n_tasks > 0;
+    range_init( fr, n_tasks > 0 );
     for( ;; )
     {
         uint32_t base = 0;
@@ -808,6 +825,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
             NodeP light_src = &sc.nodes[ light_idx ];
             MatP light_mat = &sc.mats[ light_idx ];
             V3 fov_d; double cos_rs;
+            if( sub == 0 ) cnt.cost( ACN_F_FOV + ACN_F_FRAME );   /* per task and light: booked by one lane of the group */
             obj_fov_dev( light_src, pos, &fov_d, &cos_rs );
             M3 src_con = m_transposed( m_con_z( fov_d ) );
             double cyl_hgt = 1 - cos_rs;
@@ -824,6 +842,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 uint64_t r = rvj;
                 rvj = lcg_stride< LPT >( rvj );
                 cnt.inc( CNT_CAP_SAMPLE );
+                cnt.cost( ACN_F_CAP_SAMPLE, ACN_T_CAP_SAMPLE );
                 V3 out_d = m_mlv( src_con, v_random_sphere_cap( &r, cyl_hgt ) );
                 double weight = v_mlv( out_d, surface_d );
                 if( weight <= 0 ) continue;
@@ -831,14 +850,14 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 if( LEAF_LIGHTS ) a = leaf_element_hit< false >( light_src, light_src->type, pos, out_d, nullptr, &cnt );
                 else a = light_hit_call( sc, light_idx, pos, out_d, &cnt );
                 if( a >= F3_INF ) continue;
-                if( on_b > 0 ) weight = oren_nayar_weight_pre( weight, theta_i, sin_i, cos_i, on_a, on_b, out_d, surface_d, ray_projection );
+                if( on_b > 0 ) { cnt.cost( ACN_F_OREN_NAYAR, ACN_T_OREN_NAYAR ); weight = oren_nayar_weight_pre( weight, theta_i, sin_i, cos_i, on_a, on_b, out_d, surface_d, ray_projection ); }
                 cnt.inc( CNT_SHADOW_RAY );
                 V3 hit_pos = ray_pos( pos, out_d, a );
                 double diff_sqr = v_diff_sqr( hit_pos, light_pos );
                 double local_intensity = ( diff_sqr > 0 ) ? ( radiance / diff_sqr ) : F3_MAG;
                 double c = local_intensity * weight * diffuse_intensity;
                 int occ = root_occluded_fast( scp, sc.matter_root, pos, out_d, a, &cnt );
-                if( occ == 0 ) s += c;
+                if( occ == 0 ) { s += c; cnt.cost( ACN_F_DIRECT_TAIL ); }
                 /* hard shadow rays: appended to the queue of k_hard_shadow, which adds c itself if unoccluded */
                 uint32_t hs = chunk_alloc( cs + 0, &p_counts[ QC_HARD_SHADOW ], occ == 2 );
                 if( occ == 2 )
@@ -868,6 +887,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
         /* ---- path tracing, scene.c:584-621 ---- */
         if( sc.prm.path_samples && t.depth > 10 )
         {
+            if( sub == 0 ) cnt.cost( ACN_F_FRAME );
             M3 out_con = m_transposed( m_con_z( surface_d ) );
             uint64_t path_samples = ( uint64_t )( sc.prm.path_samples * diffuse_intensity );
             path_samples = ( path_samples == 0 ) ? 1 : path_samples;
@@ -880,6 +900,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 uint64_t r = rvj;
                 rvj = lcg_stride< LPT >( rvj );
                 cnt.inc( CNT_CAP_SAMPLE );
+                cnt.cost( ACN_F_CAP_SAMPLE, ACN_T_CAP_SAMPLE );
                 V3 out_d = m_mlv( out_con, v_random_sphere_cap( &r, 1.0 ) );
                 double weight = v_mlv( out_d, surface_d );
                 bool live = weight > 0;
@@ -889,7 +910,8 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 bool hard = false;
                 if( live )
                 {
-                    if( on_b > 0 ) weight = oren_nayar_weight_pre( weight, theta_i, sin_i, cos_i, on_a, on_b, out_d, surface_d, ray_projection );
+                    if( on_b > 0 ) { cnt.cost( ACN_F_OREN_NAYAR, ACN_T_OREN_NAYAR ); weight = oren_nayar_weight_pre( weight, theta_i, sin_i, cos_i, on_a, on_b, out_d, surface_d, ray_projection ); }
+                    cnt.cost( ACN_F_PATH_TAIL );
                     a = root_trans_hit_fast( scp, sc.matter_root, pos, out_d, &trans, &hard, &cnt );
                 }
                 bool hit = live && !hard && a < sc.prm.max_path_length;
@@ -959,7 +981,7 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
     n = n < cap ? n : cap;
     n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
     FetchRange fr;
-    fr.cur = fr.end = 0; fr.more = n > 0;
+    range_init( fr, n > 0 );
     for( ;; )
     {
         uint32_t first = 0;
@@ -973,7 +995,7 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
                 bool occ;
                 if constexpr( LDS ) occ = root_occluded( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, r.limit, &cnt );
                 else                occ = root_occluded( scene_view< PRUNE >( sc, sc.nodes ), sc.matter_root, r.pos, r.d, r.limit, &cnt );
-                if( !occ ) pixel_add( accum, sc.flags, r.pixel, r.contrib );
+                if( !occ ) { cnt.cost( ACN_F_DIRECT_TAIL ); pixel_add( accum, sc.flags, r.pixel, r.contrib ); }
             }
         }
     }
@@ -1000,7 +1022,7 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
     uint32_t n_ch = 0;
     auto kill_ch = [ p_children ]( uint32_t k ) { p_children[ k ].pixel = ACN_INVALID; };
     FetchRange fr;
-    fr.cur = fr.end = 0; fr.more = n > 0;
+    range_init( fr, n > 0 );
     for( ;; )
     {
         uint32_t first = 0;

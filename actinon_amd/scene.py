@@ -277,9 +277,9 @@ class Handle:
 
     def last_counters(self):
         names = ["trans_rays", "shadow_rays", "obj_hits", "lum_calls", "cap_samples", "side_calls", "sdf_evals",
-                 "overflows"]
-        buf = (C.c_uint64 * 8)()
-        check(hip.acn_last_counters(self.h, buf, 8), "acn_last_counters")
+                 "overflows", "flop", "transcendentals"]
+        buf = (C.c_uint64 * 10)()
+        check(hip.acn_last_counters(self.h, buf, 10), "acn_last_counters")
         return dict(zip(names, [int(v) for v in buf]))
 
     def estimate_envelope(self, node, samples=1000, rseed=123, radius_factor=1.1):

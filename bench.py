@@ -49,6 +49,7 @@ WORKLOADS = {
 }
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FP64_PEAK_TFLOPS = 78.6  # fp64 vector (non-MFMA) peak = half the guide's 157.3 TFLOP/s fp32 vector peak; counts an FMA as 2
 
 
 def measured_traffic(workload, world):
@@ -103,11 +104,20 @@ def cpu_baseline(flat, width, height, path_samples, target_seconds=15.0):
     o.render_positions(flat, sample, linear=True, threads=cores)
     dt = time.perf_counter() - t0
     unit_scale = max(path_samples, 1)
+    # the reference algorithm's fp64 work per pixel (cost table of SURVEY.md App. B), counted on the probe
+    _, cnt = o.render_positions(flat, probe, linear=True, threads=cores, counters=True)
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except (OSError, IndexError):
+        model = "unknown"
     return {
         "value": sample.shape[0] * unit_scale / dt / 1e6,
         "unit": "Msamples/s" if path_samples else "Mpixels/s",
         "cores": cores,
         "kind": "port",
+        "cpu_model": model,
+        "flop_per_pixel": cnt["flop"] / probe.shape[0],
+        "transcendentals_per_pixel": cnt["transc"] / probe.shape[0],
         "sample": f"every {stride}th pixel of the {width}x{height} frame ({sample.shape[0]} pixels x {path_samples} "
                   f"path samples, {dt:.1f} s, {cores} threads)",
     }
@@ -277,6 +287,14 @@ def main():
                          "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
                          "note": "the path is fp64-VALU-issue bound with divergent CSG traversal; the HBM roofline is "
                                  "reported because BASELINE.json asks for it (DESIGN.md 7)"},
+            "roofline_fp64": None if counters is None else {
+                "bound": "fp64 vector ALU (no MFMA: the path has no dense contraction)",
+                "flop": counters["flop"], "transcendentals": counters["transcendentals"],
+                "achieved": counters["flop"] / (k_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": counters["flop"] / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "note": "flop = events the instrumented kernels executed on rank 0 x the unit costs of SURVEY.md App. B "
+                        "(actinon_amd/csrc/acn_costs.h; a transcendental call is tallied separately, not as flops); "
+                        "cpu_baseline.flop_per_pixel is the same tally of the reference's algorithm by the oracle"},
             "stages": stages,
             "work": None if counters is None else {
                 "rays_per_step_rank0": counters["trans_rays"] + counters["shadow_rays"],

@@ -59,6 +59,10 @@ typedef struct
 } ctx_t;
 
 #define COUNT( c, k ) do { if( ( c )->cnt ) ( c )->cnt[ k ]++; } while( 0 )
+/* F_alg / T_alg of SURVEY.md App. B: event costs from actinon_amd/csrc/acn_costs.h, tallied at the same places of the
+ * algorithm as by the instrumented device kernels */
+#include "../actinon_amd/csrc/acn_costs.h"
+#define COST( c, f, t ) do { if( ( c )->cnt ) { ( c )->cnt[ ORC_N_FLOP ] += ( f ); ( c )->cnt[ ORC_N_TRANSC ] += ( t ); } } while( 0 )
 
 static double f3_sqr( double a ) { return a * a; }
 static double f3_max( double a, double b ) { return a > b ? a : b; }
@@ -299,6 +303,7 @@ static void fresnel_refraction( v3 dir_i, v3 exit_nor, double trix, v3* dir )
 static double sdf_eval( ctx_t* c, const acn_node* n, v3 pos )
 {
     COUNT( c, ORC_N_SDF_EVAL );
+    COST( c, n->sdf_kind == ACN_SDF_TORUS ? ACN_F_SDF_TORUS : ACN_F_SDF_SPHERE, 0 );
     if( n->sdf_kind == ACN_SDF_TORUS )
     {
         double x = pos.x;
@@ -316,12 +321,15 @@ static double sdf_eval( ctx_t* c, const acn_node* n, v3 pos )
 static int env_ray_hits( ctx_t* c, const acn_node* n, const ray_t* r )
 {
     COUNT( c, ORC_N_ENV_TEST );
-    return sphere_ray_hit( v3_ld( n->env_pos ), n->env_radius, r, NULL ) < F3_INF;
+    int hit = sphere_ray_hit( v3_ld( n->env_pos ), n->env_radius, r, NULL ) < F3_INF;
+    COST( c, hit ? ACN_F_ENV_HIT : ACN_F_ENV_MISS, 0 );
+    return hit;
 }
 
 static int env_side( ctx_t* c, const acn_node* n, v3 pos )
 {
     COUNT( c, ORC_N_ENV_TEST );
+    COST( c, ACN_F_SIDE_SPHERE, 0 );
     return sphere_observer_side( v3_ld( n->env_pos ), n->env_radius, pos );
 }
 
@@ -399,6 +407,7 @@ static double distance_ray_hit( ctx_t* c, const acn_node* o, const ray_t* r, v3*
         if( env_side( c, o, r->p ) == 1 )
         {
             offs0 = sphere_ray_hit( v3_ld( o->env_pos ), o->env_radius, &ray, NULL );
+            COST( c, offs0 < F3_INF ? ACN_F_SPHERE_HIT : ACN_F_SPHERE_MISS, 0 );
             if( offs0 >= F3_INF ) return F3_INF;
             ray.p = ray_pos( &ray, offs0 );
         }
@@ -409,6 +418,7 @@ static double distance_ray_hit( ctx_t* c, const acn_node* o, const ray_t* r, v3*
 
     double offs1 = 0;
     double dist = sdf_eval( c, o, ray.p );
+    unsigned steps = 0;
 
     if( dist > 0 )
     {
@@ -416,6 +426,7 @@ static double distance_ray_hit( ctx_t* c, const acn_node* o, const ray_t* r, v3*
         {
             offs1 += dist + F3_EPS;
             dist = sdf_eval( c, o, ray_pos( &ray, offs1 ) );
+            steps++;
             if( dist < 0 || dist > F3_MAG ) break;
         }
     }
@@ -425,14 +436,17 @@ static double distance_ray_hit( ctx_t* c, const acn_node* o, const ray_t* r, v3*
         {
             offs1 -= dist - F3_EPS;
             dist = sdf_eval( c, o, ray_pos( &ray, offs1 ) );
+            steps++;
             if( dist > 0 || dist < -F3_MAG ) break;
         }
     }
+    COST( c, ACN_F_SDF_RAY + ACN_F_SDF_STEP * steps, 0 );
 
     if( f3_abs( dist ) <= F3_EPS )
     {
         if( p_nor )
         {
+            COST( c, ACN_F_SDF_NORMAL, 0 );
             v3 p = ray_pos( &ray, offs1 );
             double d0 = sdf_eval( c, o, p );
             v3 n;
@@ -449,6 +463,7 @@ static double distance_ray_hit( ctx_t* c, const acn_node* o, const ray_t* r, v3*
 /* objects.c:961-966 */
 static int distance_side( ctx_t* c, const acn_node* o, v3 pos )
 {
+    COST( c, ACN_F_SIDE_SDF, 0 );
     if( has_env( o ) && env_side( c, o, pos ) == 1 ) return 1;
     m3 rax = node_rax( o );
     v3 p = v3_mlf( m3_mlv( &rax, v3_sub( pos, v3_ld( o->pos ) ) ), o->prm[ 0 ] );
@@ -462,6 +477,7 @@ static double pair_ray_hit( ctx_t* c, const acn_node* o, const ray_t* r, v3* p_n
     v3 n1 = { 0, 0, 0 }, n2 = { 0, 0, 0 };
     double a1 = obj_ray_hit( c, o->child0, r, &n1 );
     double a2 = obj_ray_hit( c, o->child1, r, &n2 );
+    COST( c, ACN_F_PAIR_STEP, 0 );
     if( a1 < a2 && obj_side( c, o->child1, ray_pos( r, a1 ) ) == want )
     {
         if( p_nor ) *p_nor = n1;
@@ -469,6 +485,7 @@ static double pair_ray_hit( ctx_t* c, const acn_node* o, const ray_t* r, v3* p_n
     }
 
     if( a2 >= F3_INF ) return F3_INF;
+    COST( c, ACN_F_PAIR_STEP, 0 );
 
     if( obj_side( c, o->child0, ray_pos( r, a2 ) ) == want )
     {
@@ -486,6 +503,7 @@ static double pair_ray_hit( ctx_t* c, const acn_node* o, const ray_t* r, v3* p_n
     while( offs < F3_INF )
     {
         double a = obj_ray_hit( c, obj1, &ray, &n1 );
+        COST( c, ACN_F_PAIR_STEP, 0 );
         if( a >= F3_INF ) return F3_INF;
         if( obj_side( c, obj2, ray_pos( &ray, a ) ) == want )
         {
@@ -504,6 +522,7 @@ static double pair_ray_hit( ctx_t* c, const acn_node* o, const ray_t* r, v3* p_n
 /* objects.c:1418-1437 */
 static double scale_ray_hit( ctx_t* c, const acn_node* o, const ray_t* r, v3* p_nor )
 {
+    COST( c, ACN_F_SCALE_WRAP, 0 );
     m3 rax = node_rax( o );
     v3 inv_scale = V( o->prm[ 0 ], o->prm[ 1 ], o->prm[ 2 ] );
     ray_t ray;
@@ -530,9 +549,21 @@ static double type_ray_hit( ctx_t* c, const acn_node* o, const ray_t* ray, v3* p
 {
     switch( o->type )
     {
-        case ACN_PLANE:    COUNT( c, ORC_N_PLANE_HIT );  return plane_ray_hit( v3_ld( o->pos ), v3_ld( o->rax + 6 ), ray, p_nor ); /* objects.c:529-532 */
-        case ACN_SPHERE:   COUNT( c, ORC_N_SPHERE_HIT ); return sphere_ray_hit( v3_ld( o->pos ), o->prm[ 0 ], ray, p_nor );        /* objects.c:649-652 */
-        case ACN_SQUAROID: COUNT( c, ORC_N_SQUAROID_HIT ); return squaroid_ray_hit( o, ray, p_nor );
+        case ACN_PLANE:    COUNT( c, ORC_N_PLANE_HIT ); COST( c, ACN_F_PLANE_HIT, 0 ); return plane_ray_hit( v3_ld( o->pos ), v3_ld( o->rax + 6 ), ray, p_nor ); /* objects.c:529-532 */
+        case ACN_SPHERE:   /* objects.c:649-652 */
+        {
+            COUNT( c, ORC_N_SPHERE_HIT );
+            double a = sphere_ray_hit( v3_ld( o->pos ), o->prm[ 0 ], ray, p_nor );
+            COST( c, a < F3_INF ? ( p_nor ? ACN_F_SPHERE_HIT_NOR : ACN_F_SPHERE_HIT ) : ACN_F_SPHERE_MISS, 0 );
+            return a;
+        }
+        case ACN_SQUAROID:
+        {
+            COUNT( c, ORC_N_SQUAROID_HIT );
+            double a = squaroid_ray_hit( o, ray, p_nor );
+            COST( c, a < F3_INF ? ( p_nor ? ACN_F_SQUAROID_HIT_NOR : ACN_F_SQUAROID_HIT ) : ACN_F_SQUAROID_MISS, 0 );
+            return a;
+        }
         case ACN_DISTANCE: return distance_ray_hit( c, o, ray, p_nor );
         case ACN_PAIR_INSIDE:  return pair_ray_hit( c, o, ray, p_nor, -1 );
         case ACN_PAIR_OUTSIDE: return pair_ray_hit( c, o, ray, p_nor,  1 );
@@ -562,6 +593,7 @@ static double obj_ray_hit( ctx_t* c, int node, const ray_t* ray, v3* p_nor )
     double a = type_ray_hit( c, hdr, ray, p_nor );
     if( a < F3_INF && hdr->surface_roughness > 0 && p_nor )
     {
+        COST( c, ACN_F_ROUGHNESS, ACN_T_ROUGHNESS );
         v3 n = *p_nor;
         uint64_t rv = v3_random_seed( ray_pos( ray, a ), 1246 );
         double f;
@@ -588,9 +620,9 @@ static int obj_side( ctx_t* c, int node, v3 pos )
     if( has_env( o ) && env_side( c, o, pos ) == 1 ) return 1;
     switch( o->type )
     {
-        case ACN_PLANE:    return plane_observer_side( v3_ld( o->pos ), v3_ld( o->rax + 6 ), pos );   /* objects.c:534-537 */
-        case ACN_SPHERE:   return sphere_observer_side( v3_ld( o->pos ), o->prm[ 0 ], pos );          /* objects.c:654-657 */
-        case ACN_SQUAROID: return squaroid_side( o, pos );
+        case ACN_PLANE:    COST( c, ACN_F_SIDE_PLANE, 0 );    return plane_observer_side( v3_ld( o->pos ), v3_ld( o->rax + 6 ), pos );   /* objects.c:534-537 */
+        case ACN_SPHERE:   COST( c, ACN_F_SIDE_SPHERE, 0 );   return sphere_observer_side( v3_ld( o->pos ), o->prm[ 0 ], pos );          /* objects.c:654-657 */
+        case ACN_SQUAROID: COST( c, ACN_F_SIDE_SQUAROID, 0 ); return squaroid_side( o, pos );
         case ACN_DISTANCE: return distance_side( c, o, pos );
         case ACN_PAIR_INSIDE:  /* objects.c:1096-1099 */
             return ( obj_side( c, o->child0, pos ) + obj_side( c, o->child1, pos ) == -2 ) ? -1 : 1;
@@ -600,6 +632,7 @@ static int obj_side( ctx_t* c, int node, v3 pos )
             return -1 * obj_side( c, o->child0, pos );
         case ACN_SCALE:        /* objects.c:1439-1443 */
         {
+            COST( c, ACN_F_SIDE_SCALE, 0 );
             m3 rax = node_rax( o );
             v3 p = m3_mlv( &rax, v3_sub( pos, v3_ld( o->pos ) ) );
             return obj_side( c, o->child0, v3_mld( p, V( o->prm[ 0 ], o->prm[ 1 ], o->prm[ 2 ] ) ) );
@@ -749,6 +782,7 @@ static double compound_ray_trans_hit( ctx_t* c, int cmp, const ray_t* ray, trans
 
         if( a < F3_INF )
         {
+            COST( c, ACN_F_TRANS_RESOLVE, 0 );
             if( a < min_a - F3_EPS )
             {
                 min_a = a;
@@ -807,6 +841,7 @@ static double scene_trans_hit( ctx_t* c, const ray_t* r, trans_t* trans )
 static double oren_nayar_weight( ctx_t* c, double weight, double theta_i, double on_a, double on_b, v3 out_d, v3 nor, v3 ray_prj )
 {
     COUNT( c, ORC_N_OREN_NAYAR );
+    COST( c, ACN_F_OREN_NAYAR, ACN_T_OREN_NAYAR );
     double theta_r = M_ACOS( weight );
     double cos_phi = -v3_mlv( v3_of_length( v3_orthogonal_projection( out_d, nor ), 1.0 ), ray_prj );
     return weight *
@@ -830,6 +865,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
     v3 lum = { 0, 0, 0 };
     if( depth == 0 || intensity < scene->trace_min_intensity ) return lum;
     COUNT( c, ORC_N_LUM );
+    COST( c, ACN_F_LUM_FIXED, 0 );
 
     v3 pos = ray_pos( ray, offs );
     const acn_node* enter_obj = trans->enter_obj >= 0 ? &nodes[ trans->enter_obj ] : NULL;
@@ -839,6 +875,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
     {
         double diff_sqr = v3_diff_sqr( pos, v3_ld( enter_obj->pos ) );
         double light_intensity = ( diff_sqr > 0 ) ? ( enter_obj->radiance / diff_sqr ) : F3_MAG;
+        COST( c, ACN_F_EMISSION, 0 );
         return v3_mlf( obj_color( c->sc, enter_obj, pos ), light_intensity * intensity );
     }
 
@@ -882,6 +919,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
     if( fresnel_reflectivity > 0 && intensity >= scene->trace_min_intensity )
     {
         COUNT( c, ORC_N_FRESNEL );
+        COST( c, ACN_F_FRESNEL_REFL, 0 );
         ray_t out;
         out.p = pos;
         double reflectance = fresnel_reflection( ray->d, trans->exit_nor, trans_refractive_index, &out.d ) * fresnel_reflectivity;
@@ -906,6 +944,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
     {
         ray_t out;
         out.p = pos;
+        COST( c, ACN_F_REFLECTION, 0 );
         out.d = v3_reflection( ray->d, trans->exit_nor );
         trans_t trans_l = { { 0, 0, 0 }, -1, -1 };
         double a;
@@ -930,6 +969,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
     {
         double diffuse_intensity = intensity * diffuse_reflectivity;
         ray_t surface = { pos, v3_neg( trans->exit_nor ) };
+        COST( c, ACN_F_SHADE_DIFFUSE + ACN_F_SEED, ACN_T_SHADE_DIFFUSE + ACN_T_SEED );
 
         double theta_i = M_ACOS( -v3_mlv( ray->d, surface.d ) );
         v3 ray_projection = v3_of_length( v3_orthogonal_projection( ray->d, surface.d ), 1.0 );
@@ -945,6 +985,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
             ray_t out = surface;
             int light_idx = c->sc->elems[ light->child0 + i ];
             const acn_node* light_src = &nodes[ light_idx ];
+            COST( c, ACN_F_FOV + ACN_F_FRAME, 0 );
             cone_t fov_to_src = obj_fov( light_src, pos );
             m3 src_con = m3_transposed( m3_con_z( fov_to_src.ray.d ) );
             double cyl_hgt = 1 - fov_to_src.cos_rs; /* areal_coverage vectors.h:362 */
@@ -955,6 +996,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
             for( uint64_t j = 0; j < direct_samples; j++ )
             {
                 COUNT( c, ORC_N_CAP_SAMPLE );
+                COST( c, ACN_F_CAP_SAMPLE, ACN_T_CAP_SAMPLE );
                 out.d = m3_mlv( &src_con, v3_random_sphere_cap( &rv, cyl_hgt ) );
                 double weight = v3_mlv( out.d, surface.d );
                 if( weight <= 0 ) continue;
@@ -967,6 +1009,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
                 COUNT( c, ORC_N_SHADOW_RAY );
                 if( compound_ray_hit( c, c->sc->matter_root, &out, NULL, NULL ) > a )
                 {
+                    COST( c, ACN_F_DIRECT_TAIL, 0 );
                     v3 hit_pos = ray_pos( &out, a );
                     double diff_sqr = v3_diff_sqr( hit_pos, v3_ld( light_src->pos ) );
                     double local_intensity = ( diff_sqr > 0 ) ? ( light_src->radiance / diff_sqr ) : F3_MAG;
@@ -981,6 +1024,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
         {
             v3 cl_sum = { 0, 0, 0 };
             ray_t out = surface;
+            COST( c, ACN_F_FRAME, 0 );
             m3 out_con = m3_transposed( m3_con_z( surface.d ) );
 
             uint64_t path_samples = ( uint64_t )( scene->path_samples * diffuse_intensity );
@@ -989,9 +1033,11 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
             for( uint64_t i = 0; i < path_samples; i++ )
             {
                 COUNT( c, ORC_N_CAP_SAMPLE );
+                COST( c, ACN_F_CAP_SAMPLE, ACN_T_CAP_SAMPLE );
                 out.d = m3_mlv( &out_con, v3_random_sphere_cap( &rv, 1.0 ) );
                 double weight = v3_mlv( out.d, surface.d );
                 if( weight <= 0 ) continue;
+                COST( c, ACN_F_PATH_TAIL, 0 );
 
                 if( on_b > 0 ) weight = oren_nayar_weight( c, weight, theta_i, on_a, on_b, out.d, surface.d, ray_projection );
 
@@ -1024,6 +1070,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
     {
         ray_t out;
         out.p = ray_pos( ray, offs + 2.0 * F3_EPS );
+        COST( c, ACN_F_FRESNEL_REFR, 0 );
         fresnel_refraction( ray->d, trans->exit_nor, trans_refractive_index, &out.d );
 
         trans_t trans_l = { { 0, 0, 0 }, -1, -1 };
@@ -1043,6 +1090,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
     /* exiting object :656-664 */
     if( exit_obj )
     {
+        if( offs > 0 ) COST( c, ACN_F_ABSORB, ACN_T_ABSORB );
         double rf = offs > 0 ? M_POW( exit_obj->transparency[ 0 ], offs ) : 1.0;
         double gf = offs > 0 ? M_POW( exit_obj->transparency[ 1 ], offs ) : 1.0;
         double bf = offs > 0 ? M_POW( exit_obj->transparency[ 2 ], offs ) : 1.0;
@@ -1095,6 +1143,7 @@ static v3 sample_position( ctx_t* c, const camera_t* cam, double monitor_x, doub
     ray_t ray;
     ray.p = v3_ld( s->camera_position );
     ray.d = m3_mlv( &cam->camera_rotation, d );
+    COST( c, ACN_F_CAMERA_RAY, 0 );
 
     v3 out_clr = v3_ld( s->background_color );
     trans_t trans_l = { { 0, 0, 0 }, -1, -1 };

@@ -45,6 +45,8 @@ enum
     ORC_N_OREN_NAYAR,
     ORC_N_FRESNEL,
     ORC_N_NODE_VISIT,     /* nodes touched by ray traversal */
+    ORC_N_FLOP,           /* F_alg: sum of event costs (actinon_amd/csrc/acn_costs.h) */
+    ORC_N_TRANSC,         /* T_alg: transcendental calls */
     ORC_N_COUNTERS
 };
 

@@ -8,7 +8,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 COUNTER_NAMES = ["lum", "trans_ray", "shadow_ray", "obj_hit", "env_test", "plane_hit", "sphere_hit", "squaroid_hit",
-                 "sdf_ray", "sdf_eval", "pair_hit", "side", "cap_sample", "oren_nayar", "fresnel", "node_visit"]
+                 "sdf_ray", "sdf_eval", "pair_hit", "side", "cap_sample", "oren_nayar", "fresnel", "node_visit", "flop", "transc"]
 
 
 class Oracle:
