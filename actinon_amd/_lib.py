@@ -23,7 +23,8 @@ host = _load("libactinon_host.so")
 # symbols declared by include/actinon_hip.h
 HIP_SYMBOLS = ["acn_device_count", "acn_scene_upload", "acn_scene_free", "acn_render_positions",
                "acn_render_positions_dev", "acn_render_main_pass_dev", "acn_resolve_dev", "acn_last_kernel_ms", "acn_last_stage_ms", "acn_last_counters",
-               "acn_estimate_envelope", "acn_detmath_eval", "acn_last_error"]
+               "acn_estimate_envelope", "acn_detmath_eval", "acn_last_error", "acn_shard_tile_count", "acn_shard_tile_padded",
+               "acn_shard_tile_index", "acn_render_main_pass_shard_dev", "acn_shard_unpack_dev"]
 # symbols declared by include/acn_scene.h
 HOST_SYMBOLS = ["acn_rotx", "acn_roty", "acn_rotz", "acn_obj_plane_s_create", "acn_obj_sphere_s_create",
                 "acn_obj_squaroid_s_create_squaroid", "acn_obj_squaroid_s_create_ellipsoid",
@@ -65,6 +66,14 @@ hip.acn_last_counters.argtypes = [vp, P(C.c_uint64), C.c_int]
 hip.acn_estimate_envelope.argtypes = [vp, C.c_int32, C.c_uint64, C.c_uint32, C.c_double, P(C.c_double)]
 hip.acn_detmath_eval.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_size_t]
 hip.acn_last_error.restype = C.c_char_p
+hip.acn_shard_tile_count.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32]
+hip.acn_shard_tile_count.restype = C.c_size_t
+hip.acn_shard_tile_padded.argtypes = [C.c_size_t, C.c_uint32]
+hip.acn_shard_tile_padded.restype = C.c_size_t
+hip.acn_shard_tile_index.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t]
+hip.acn_shard_tile_index.restype = C.c_size_t
+hip.acn_render_main_pass_shard_dev.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, vp, P(abi.RenderOpts)]
+hip.acn_shard_unpack_dev.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp, P(abi.RenderOpts)]
 
 for _n in ["acn_rotx", "acn_roty", "acn_rotz"]:
     getattr(host, _n).argtypes = [C.c_double]

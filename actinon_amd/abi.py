@@ -5,6 +5,8 @@ ACN_ABI_VERSION = 2
 ACN_OPT_LINEAR_OUT = 1
 ACN_OPT_COUNT_WORK = 2
 ACN_OPT_STAGE_TIMING = 4
+ACN_SHARD_NONE, ACN_SHARD_SAMPLES = 0, 1
+ACN_SHARD_TILE = 256
 
 ACN_OK, ACN_ERR_ARG, ACN_ERR_UNSUPPORTED, ACN_ERR_NO_FOV, ACN_ERR_DEVICE, ACN_ERR_CANCELLED = 0, -1, -2, -3, -4, -5
 
@@ -46,7 +48,8 @@ class FlatScene(C.Structure):
 
 
 class RenderOpts(C.Structure):
-    _fields_ = [("flags", C.c_uint32), ("reserved", C.c_int32), ("cancel", C.POINTER(C.c_int)), ("stream", C.c_void_p)]
+    _fields_ = [("flags", C.c_uint32), ("reserved", C.c_int32), ("cancel", C.POINTER(C.c_int)), ("stream", C.c_void_p),
+                ("shard_mode", C.c_uint32), ("shard_rank", C.c_uint32), ("shard_world", C.c_uint32), ("reserved2", C.c_uint32)]
 
 
 class V3(C.Structure):

@@ -37,6 +37,8 @@ struct LevelQ
     uint32_t fetch_walk, fetch_hard;                        /* input items a wave reserves per cursor atomic */
     uint32_t fetch_shade;                                   /* k_shade: steps of 64 / LPT tasks a wave reserves per atomic */
     uint32_t private_limit;                                 /* generations of at most this many rays are finished on private stacks */
+    uint32_t shard_rank, shard_world;                       /* ACN_SHARD_SAMPLES at level 0: the rank's share of the sample loops; else 0, 1 */
+    uint32_t emit_terms;                                    /* 0: k_walk drops its pixel terms (level 0 of a rank > 0 of such a call) */
 };
 
 /* pass `pass` of the specular walk of the level.  n_cam > 0 (pass 0 of level 0): the input are the camera rays of
@@ -66,7 +68,7 @@ void acn_launch_hard_path( KernelFlags f, const LevelQ& q, size_t lds_bytes, hip
     hipLaunchKernelGGL( ( k_walk< C, L, R > ), dim3( q.grid ), dim3( 256 ), lds_bytes, stream, ACN_SCENE_ARGS_OF( s ), ACN_TASKQ_ARGS_OF( q ), \
         n_cam ? ( const RayTask* )nullptr : ( const RayTask* )q.rays[ pass & 1 ], q.ray_cap, pass, pos_xy, first_pixel, base, n_cam, order, \
         q.rays[ ( pass + 1 ) & 1 ], q.ray_cap, last ? 0xFFFFFFFFu : q.private_limit, \
-        q.stacks, q.stack_cap, last ? q.stack_cap : q.stack_use, q.fetch_walk, accum, counters )
+        q.stacks, q.stack_cap, last ? q.stack_cap : q.stack_use, q.fetch_walk, q.emit_terms, accum, counters )
 
 /* body of acn_launch_shade<LPT>: shared by the four k_shade translation units */
 #define ACN_DEFINE_LAUNCH_SHADE( NAME, LPT, CLS ) \
@@ -78,6 +80,6 @@ void NAME( KernelFlags f, const LevelQ& q, hipStream_t stream, const SceneArgs& 
     else               { if( f.leaf_lights ) ACN_LS_( LPT, CLS, false, true, false ); else ACN_LS_( LPT, CLS, false, false, false ); } \
 }
 #define ACN_LS_( LPT, CLS, C, L, P ) hipLaunchKernelGGL( ( k_shade< LPT, C, L, P > ), dim3( q.shade_grid ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS_OF( s ), \
-    ( const DTask* )q.tasks, ( const uint32_t* )q.idx[ CLS ], CLS, q.task_cap, q.fetch_shade * ( 64u / LPT ), q.children, q.child_cap, q.hard_shadow, q.hard_path, q.hard_cap, q.counts, accum, counters )
+    ( const DTask* )q.tasks, ( const uint32_t* )q.idx[ CLS ], CLS, q.task_cap, q.fetch_shade * ( 64u / LPT ), q.children, q.child_cap, q.hard_shadow, q.hard_path, q.hard_cap, q.counts, q.shard_rank, q.shard_world, accum, counters )
 
 #endif

@@ -596,13 +596,14 @@ struct TileOrder
  *     used); the wave works in steps of 64 rays -- the top of its stack, topped up with fresh input -- until both are
  *     empty, so the tail of a level, up to trace_depth generations of a few rays each, costs no further launch.  Rays
  *     that do not fit the stack join rays_out.
- * The host enqueues a fixed number of passes per level blind; passes whose input is empty exit at once. */
+ * The host enqueues a fixed number of passes per level blind; passes whose input is empty exit at once.
+ * emit_terms: 0 drops the pixel terms of this launch (ACN_SHARD_SAMPLES, level 0, rank > 0). */
 template< bool COUNT, bool LDS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_TRACE_WAVES )
 void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ rays_in, uint32_t in_cap, uint32_t pass,
              const double* __restrict__ pos_xy, size_t first_pixel, uint32_t base, uint32_t n_cam, TileOrder order,
              RayTask* __restrict__ rays_out, uint32_t out_cap, uint32_t private_limit,
-             RayTask* __restrict__ stacks, uint32_t stack_stride, uint32_t stack_cap, uint32_t fetch_batch,
+             RayTask* __restrict__ stacks, uint32_t stack_stride, uint32_t stack_cap, uint32_t fetch_batch, uint32_t emit_terms,
              unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_CHUNK_STATES
@@ -687,7 +688,9 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
         V3 acc = mk( 0, 0, 0 );
         if( live && !hit ) acc = v_mld( T, v_mlf( ld3( sc.prm.background_color ), intensity ) );
         shade_hit( sc, sink, tq, cs, rp, rd, hit ? offs : 0.0, trans, hit ? depth : 0, intensity, T, pixel, acc, &cnt );
-        if( live ) pixel_add( accum, sc.flags, pixel, acc );
+        /* emit_terms == 0: level 0 of a rank > 0 of a sample-sharded call -- emission / background reached through
+         * specular chains are under no sharded loop and come from rank 0 alone */
+        if( live && emit_terms ) pixel_add( accum, sc.flags, pixel, acc );
         /* the wave reads next what it wrote last: same wave, program order; the fence keeps the compiler from moving the
          * next step's loads above this step's stores */
         __builtin_amdgcn_fence( __ATOMIC_SEQ_CST, "wavefront" );
@@ -772,7 +775,7 @@ template< int LPT, bool COUNT, bool LEAF_LIGHTS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_SHADE_WAVES )
 void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t* __restrict__ idx, int cls, uint32_t task_cap, uint32_t fetch_batch,
               HitRec* __restrict__ p_children, uint32_t child_cap, HardShadow* __restrict__ p_hard_shadow,
-              HardPath* __restrict__ p_hard_path, uint32_t hard_cap, uint32_t* __restrict__ p_counts,
+              HardPath* __restrict__ p_hard_path, uint32_t hard_cap, uint32_t* __restrict__ p_counts, uint32_t shard_rank, uint32_t shard_world,
               unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_CHUNK_STATES
@@ -836,8 +839,17 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
             const V3 light_color = obj_color_dev( sc, light_idx, light_pos );   /* scene.c:552 */
 
             double s = 0;
-            uint64_t rvj = lcg_jump_lane( rv, sub );
-            for( uint64_t j = sub; j < direct_samples; j += LPT )
+            /* ACN_SHARD_SAMPLES (shard_world > 1, level 0 only): this rank's share of the loop; sample j keeps its
+             * place in the LCG stream and the normalisation below keeps the whole loop's n */
+            uint64_t j_lo = 0, j_hi = direct_samples;
+            uint64_t rv0 = rv;
+            if( shard_world > 1 )
+            {
+                j_lo = direct_samples * shard_rank / shard_world; j_hi = direct_samples * ( shard_rank + 1 ) / shard_world;
+                rv0 = lcg00_jump( rv, 2 * j_lo );
+            }
+            uint64_t rvj = lcg_jump_lane( rv0, sub );
+            for( uint64_t j = j_lo + sub; j < j_hi; j += LPT )
             {
                 uint64_t r = rvj;
                 rvj = lcg_stride< LPT >( rvj );
@@ -894,8 +906,15 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
             const double norm = 2.0 / path_samples;
             const V3 Tchild = v_mlf( ldc( t.Tc ), norm );
             double bsum = 0;
-            uint64_t rvj = lcg_jump_lane( rv, sub );
-            for( uint64_t j = sub; j < path_samples; j += LPT )
+            uint64_t j_lo = 0, j_hi = path_samples;
+            uint64_t rv0 = rv;
+            if( shard_world > 1 )
+            {
+                j_lo = path_samples * shard_rank / shard_world; j_hi = path_samples * ( shard_rank + 1 ) / shard_world;
+                rv0 = lcg00_jump( rv, 2 * j_lo );
+            }
+            uint64_t rvj = lcg_jump_lane( rv0, sub );
+            for( uint64_t j = j_lo + sub; j < j_hi; j += LPT )
             {
                 uint64_t r = rvj;
                 rvj = lcg_stride< LPT >( rvj );

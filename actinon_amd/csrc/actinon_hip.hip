@@ -155,6 +155,7 @@ struct acn_scene_handle
     bool prune = false;                        /* some root element has an interval-prune program: launch the PRUNE kernel variants */
     bool leaf_lights = true;                   /* every light element is a plane / sphere */
     bool count_work = false;                   /* ACN_OPT_COUNT_WORK of the current call */
+    uint32_t shard_rank = 0, shard_world = 1;  /* ACN_SHARD_SAMPLES of the current call */
     uint64_t launches[ 4 ] = { 0, 0, 0, 0 };   /* walk, shade, finalize, hard-ray kernels */
     uint64_t hard_rays = 0, walk_steps = 0, walk_rays = 0, shade_hit_recs = 0, host_syncs = 0, private_rays = 0;
     uint32_t flags_seen = 0;                   /* ACN_FLAG_* bits of the last call */
@@ -169,6 +170,7 @@ struct acn_scene_handle
     LaneWorker* worker = nullptr;              /* of a lane */
     size_t scene_bytes[ 4 ] = { 0, 0, 0, 0 };
     double* d_lane_pos = nullptr; double* d_lane_out = nullptr; size_t lane_buf_cap = 0;   /* a lane's gathered positions / results */
+    double* d_shard_pos = nullptr; size_t shard_pos_cap = 0;                                /* acn_render_main_pass_shard_dev: the rank's positions */
     std::string lane_error;
     bool used_lanes = false;                   /* the last render call ran through the lanes: statistics are their sums */
 };
@@ -785,6 +787,7 @@ extern "C" void acn_scene_free( acn_scene_handle* h )
     if( h->d_accum ) hipFree( h->d_accum );
     if( h->d_lane_pos ) hipFree( h->d_lane_pos );
     if( h->d_lane_out ) hipFree( h->d_lane_out );
+    if( h->d_shard_pos ) hipFree( h->d_shard_pos );
     if( !h->is_lane )   /* a lane borrows the resident scene of its parent */
     {
         if( h->d_nodes ) hipFree( h->d_nodes );
@@ -902,6 +905,10 @@ static LevelQ level_queues( const acn_scene_handle* h, int level )
     q.prev_children = h->d_counts + ( size_t )( level > 0 ? level - 1 : 0 ) * QC_N + QC_CHILDREN;
     q.grid = h->grid; q.shade_grid = h->shade_grid;
     q.fetch_walk = h->tun.fetch_walk; q.fetch_hard = h->tun.fetch_hard; q.private_limit = h->tun.private_limit; q.fetch_shade = h->tun.fetch_shade;
+    /* the outermost sample loops are those of level 0 */
+    const bool sharded = level == 0 && h->shard_world > 1;
+    q.shard_rank = sharded ? h->shard_rank : 0u; q.shard_world = sharded ? h->shard_world : 1u;
+    q.emit_terms = sharded && h->shard_rank != 0 ? 0u : 1u;
     return q;
 }
 static size_t machine_lds_bytes( const acn_scene_handle* h ) { return h->lds_bytes + h->lds_stack_bytes; }
@@ -993,6 +1000,13 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     if( n > 0xFFFFFF00ull ) return fail( ACN_ERR_ARG, "too many positions in one call" );
     int linear = ( opts && ( opts->flags & ACN_OPT_LINEAR_OUT ) ) ? 1 : 0;
     h->count_work = ( opts && ( opts->flags & ACN_OPT_COUNT_WORK ) ) || h->tun.count_work;
+    h->shard_rank = 0; h->shard_world = 1;
+    if( opts && opts->shard_mode == ACN_SHARD_SAMPLES && opts->shard_world > 1 )
+    {
+        if( opts->shard_rank >= opts->shard_world ) return fail( ACN_ERR_ARG, "shard_rank >= shard_world" );
+        h->shard_rank = opts->shard_rank; h->shard_world = opts->shard_world;
+    }
+    else if( opts && opts->shard_mode > ACN_SHARD_SAMPLES ) return fail( ACN_ERR_ARG, "unknown shard_mode" );
     h->stage_timing = ( opts && ( opts->flags & ACN_OPT_STAGE_TIMING ) ) || h->tun.stage_timing;
     int st = ensure_workspace( h, n );
     if( st != ACN_OK ) return st;
@@ -1303,6 +1317,77 @@ extern "C" int acn_render_positions( acn_scene_handle* h, const double* pos_xy, 
     if( st == ACN_OK && hipMemcpy( out_rgb, d_out, sizeof( double ) * 3 * n, hipMemcpyDeviceToHost ) != hipSuccess ) st = fail( ACN_ERR_DEVICE, "D2H copy failed" );
     hipFree( d_pos ); hipFree( d_out );
     return st;
+}
+
+/* ---- sharding of whole positions: tiles of ACN_SHARD_TILE, round-robin (plain arithmetic, no GPU) ---- */
+extern "C" size_t acn_shard_tile_count( size_t n, uint32_t rank, uint32_t world )
+{
+    if( world <= 1 ) return rank == 0 ? n : 0;
+    return rank < world ? lane_count( n, ( int )world, ( int )rank ) : 0;
+}
+extern "C" size_t acn_shard_tile_padded( size_t n, uint32_t world )
+{
+    if( world <= 1 ) return n;
+    size_t tiles = ( n + ACN_SHARD_TILE - 1 ) / ACN_SHARD_TILE;
+    return ( ( tiles + world - 1 ) / world ) * ACN_SHARD_TILE;
+}
+extern "C" size_t acn_shard_tile_index( size_t n, uint32_t rank, uint32_t world, size_t i )
+{
+    ( void )n;
+    if( world <= 1 ) return i;
+    return ( ( i / ACN_SHARD_TILE ) * world + rank ) * ACN_SHARD_TILE + ( i % ACN_SHARD_TILE );
+}
+
+__global__ void k_shard_unpack( const double* __restrict__ gathered, size_t n, uint32_t world, size_t padded, double* __restrict__ frame )
+{
+    size_t g = ( size_t )blockIdx.x * blockDim.x + threadIdx.x;
+    if( g >= n ) return;
+    size_t tile = g / ACN_SHARD_TILE;
+    size_t r = tile % world, i = ( tile / world ) * ACN_SHARD_TILE + g % ACN_SHARD_TILE;
+    const double* src = gathered + ( r * padded + i ) * 3;
+    frame[ g * 3 ] = src[ 0 ]; frame[ g * 3 + 1 ] = src[ 1 ]; frame[ g * 3 + 2 ] = src[ 2 ];
+}
+
+extern "C" int acn_render_main_pass_shard_dev( acn_scene_handle* h, size_t first, size_t count, uint32_t rank, uint32_t world,
+                                               void* d_part, const acn_render_opts* opts )
+{
+    if( !h || ( count && !d_part ) || world == 0 || rank >= world ) return fail( ACN_ERR_ARG, "bad argument" );
+    if( first + count > h->dev.prm.image_width * h->dev.prm.image_height ) return fail( ACN_ERR_ARG, "pixel range outside the image" );
+    HIP_TRY( hipSetDevice( h->device ) );
+    hipStream_t stream = ( opts && opts->stream ) ? ( hipStream_t )opts->stream : h->stream;
+    const size_t mine = acn_shard_tile_count( count, rank, world ), padded = acn_shard_tile_padded( count, world );
+    if( padded > mine ) HIP_TRY( hipMemsetAsync( ( double* )d_part + 3 * mine, 0, sizeof( double ) * 3 * ( padded - mine ), stream ) );
+    if( mine )
+    {
+        if( h->shard_pos_cap < mine )
+        {
+            if( h->d_shard_pos ) hipFree( h->d_shard_pos );
+            h->d_shard_pos = nullptr; h->shard_pos_cap = 0;
+            HIP_TRY( hipMalloc( &h->d_shard_pos, sizeof( double ) * 2 * mine ) );
+            h->shard_pos_cap = mine;
+        }
+        hipLaunchKernelGGL( k_lane_gather, dim3( ( unsigned )( ( mine + 255 ) / 256 ) ), dim3( 256 ), 0, stream,
+                            ( const double* )nullptr, first, ( uint64_t )h->dev.prm.image_width, mine, ( int )world, ( int )rank, h->d_shard_pos );
+        HIP_TRY( hipGetLastError() );
+        int st = render_dispatch( h, h->d_shard_pos, 0, mine, ( double* )d_part, opts, stream );
+        if( st != ACN_OK ) return st;
+    }
+    if( !( opts && opts->stream ) ) HIP_TRY( hipStreamSynchronize( stream ) );
+    return ACN_OK;
+}
+
+extern "C" int acn_shard_unpack_dev( acn_scene_handle* h, const void* d_gathered, size_t count, uint32_t world, void* d_frame,
+                                     const acn_render_opts* opts )
+{
+    if( !h || ( count && ( !d_gathered || !d_frame ) ) || world == 0 ) return fail( ACN_ERR_ARG, "bad argument" );
+    if( count == 0 ) return ACN_OK;
+    HIP_TRY( hipSetDevice( h->device ) );
+    hipStream_t stream = ( opts && opts->stream ) ? ( hipStream_t )opts->stream : h->stream;
+    hipLaunchKernelGGL( k_shard_unpack, dim3( ( unsigned )( ( count + 255 ) / 256 ) ), dim3( 256 ), 0, stream,
+                        ( const double* )d_gathered, count, world, acn_shard_tile_padded( count, world ), ( double* )d_frame );
+    HIP_TRY( hipGetLastError() );
+    if( !( opts && opts->stream ) ) HIP_TRY( hipStreamSynchronize( stream ) );
+    return ACN_OK;
 }
 
 extern "C" int acn_resolve_dev( acn_scene_handle* h, const void* d_linear_rgb, size_t n, void* d_out_rgb, void* d_out_rgb8,

@@ -219,6 +219,7 @@ class Handle:
         self.count_work = count_work   # instrumented kernels: last_counters() is only meaningful when set
         self.stage_timing = False      # per-launch HIP events: last_stages() then carries walk / shade / hard ms
         self.cancel = None             # optional ctypes.c_int polled by the library (acn_render_opts.cancel)
+        self.sample_shard = None       # (rank, world): ACN_SHARD_SAMPLES for the following render calls (linear output)
         self.h = C.c_void_p()
         check(hip.acn_scene_upload(C.byref(flat.c), device, C.byref(self.h)), "acn_scene_upload")
 
@@ -237,6 +238,9 @@ class Handle:
         o.stream = stream
         if self.cancel is not None:
             o.cancel = C.pointer(self.cancel)
+        if self.sample_shard is not None:
+            o.shard_mode = abi.ACN_SHARD_SAMPLES
+            o.shard_rank, o.shard_world = self.sample_shard
         return o
 
     def render_positions(self, pos_xy, linear=False):
@@ -255,6 +259,16 @@ class Handle:
     def render_main_pass_dev(self, first, count, d_out_ptr, linear=False, stream=None):
         o = self._opts(linear, stream)
         check(hip.acn_render_main_pass_dev(self.h, first, count, d_out_ptr, C.byref(o)), "acn_render_main_pass_dev")
+
+    def render_main_pass_shard_dev(self, first, count, rank, world, d_part_ptr, linear=True, stream=None):
+        """This rank's tiles of the main pass (acn_shard_tile_*), into a part of acn_shard_tile_padded(count, world) rows."""
+        o = self._opts(linear, stream)
+        check(hip.acn_render_main_pass_shard_dev(self.h, first, count, rank, world, d_part_ptr, C.byref(o)),
+              "acn_render_main_pass_shard_dev")
+
+    def shard_unpack_dev(self, d_gathered_ptr, count, world, d_frame_ptr, stream=None):
+        o = self._opts(True, stream)
+        check(hip.acn_shard_unpack_dev(self.h, d_gathered_ptr, count, world, d_frame_ptr, C.byref(o)), "acn_shard_unpack_dev")
 
     def resolve_dev(self, d_linear_ptr, n, d_out_rgb_ptr=None, d_out_rgb8_ptr=None, stream=None):
         """cl_s_sat + 8-bit pack on a device-resident linear radiance buffer (after accumulation / all-reduce)."""

@@ -152,12 +152,30 @@ typedef struct acn_flat_scene
 #define ACN_OPT_COUNT_WORK 2u   /* run the instrumented kernels: acn_last_counters() reports rays / samples / hit tests */
 #define ACN_OPT_STAGE_TIMING 4u /* record HIP events around every launch: acn_last_stage_ms() reports per-stage times */
 
+/* Sharding of one call over the ranks of a multi-GPU job (one process per GPU).  The reference has one process and
+ * no counterpart; what shards is what its pixel farm makes independent (src/scene.c:976-1011): sample positions, and
+ * inside a position the iterations of the outermost sample loops (src/scene.c:556,596).
+ *   ACN_SHARD_SAMPLES  every rank renders every position of the call, but of each OUTERMOST direct-light loop and path
+ *                      loop only the iterations [ n * rank / world, n * ( rank + 1 ) / world ) -- n, the normalisation
+ *                      2 * cyl_hgt / n resp. 2 / n and the LCG stream position of an iteration stay those of the whole
+ *                      loop.  Terms that are under no such loop (emission and background reached through specular
+ *                      chains, src/scene.c:432-437,488-491,511-514,648-651; a camera ray that hits nothing) come from
+ *                      rank 0 alone.  Out: LINEAR partial radiance (use ACN_OPT_LINEAR_OUT); the caller sum-reduces the
+ *                      ranks' buffers and then applies acn_resolve_dev.  For few positions with many samples.
+ * Whole positions are sharded with the acn_shard_tile_* functions below (disjoint supports, no floating-point reduce). */
+#define ACN_SHARD_NONE    0u
+#define ACN_SHARD_SAMPLES 1u
+
 typedef struct acn_render_opts
 {
     uint32_t flags;
     int32_t  reserved;
     const volatile int* cancel;    /* optional; polled between launches; the SIGINT flag of src/scene.c:893,978 */
     void*    stream;               /* optional hipStream_t; NULL = the handle's own stream */
+    uint32_t shard_mode;           /* ACN_SHARD_* */
+    uint32_t shard_rank;           /* 0 .. shard_world - 1 */
+    uint32_t shard_world;          /* 0 or 1: the call is not sharded */
+    uint32_t reserved2;
 } acn_render_opts;
 
 typedef struct acn_scene_handle acn_scene_handle;
@@ -196,6 +214,26 @@ int acn_render_positions_dev( acn_scene_handle* h, const void* d_pos_xy, size_t 
  * for the pixel sub-range [first, first+count) of the image_width x image_height raster. */
 int acn_render_main_pass_dev( acn_scene_handle* h, size_t first, size_t count, void* d_out_rgb,
                               const acn_render_opts* opts );
+
+/* Sharding of whole positions: the n positions of a call (or pixels of a frame) are cut into tiles of ACN_SHARD_TILE
+ * consecutive positions dealt round-robin to the ranks -- interleaving balances sky, floor and glass between them.
+ * These three are plain arithmetic (no GPU): */
+#define ACN_SHARD_TILE 256
+/* number of positions rank `rank` of `world` owns */
+size_t acn_shard_tile_count( size_t n, uint32_t rank, uint32_t world );
+/* common length of the ranks' parts for an all-gather: the largest count, i.e. ceil( ceil( n / TILE ) / world ) * TILE */
+size_t acn_shard_tile_padded( size_t n, uint32_t world );
+/* index in [ 0, n ) of the i-th position of the rank's part (i < acn_shard_tile_count) */
+size_t acn_shard_tile_index( size_t n, uint32_t rank, uint32_t world, size_t i );
+
+/* Main pass of rank `rank`: renders the rank's tiles of the pixel range [ first, first + count ) (acn_render_main_pass_dev's
+ * positions) into d_part, [ acn_shard_tile_padded( count, world ) ][ 3 ] f64, part order, zero behind the rank's count. */
+int acn_render_main_pass_shard_dev( acn_scene_handle* h, size_t first, size_t count, uint32_t rank, uint32_t world,
+                                    void* d_part, const acn_render_opts* opts );
+/* After the all-gather of the ranks' parts (d_gathered: [ world ][ padded ][ 3 ] f64, rank-major): the frame
+ * d_frame[ count ][ 3 ] in position order.  Every value is copied, none is added: bit-identical to one GPU. */
+int acn_shard_unpack_dev( acn_scene_handle* h, const void* d_gathered, size_t count, uint32_t world, void* d_frame,
+                          const acn_render_opts* opts );
 
 /* cl_s_sat (src/vectors.h:372-384) + cps_from_cl (src/scene.c:76-82) on a device-resident LINEAR radiance buffer,
  * e.g. after the cross-GPU sum-reduce: d_out_rgb (nullable) receives the gamma-saturated colours [n][3] f64,

@@ -56,7 +56,18 @@ typedef struct
 {
     const acn_flat_scene* sc;
     uint64_t* cnt; /* nullable */
+    /* ACN_SHARD_SAMPLES (include/actinon_hip.h): this evaluation contributes rank `rank` of `world`'s share -- of the
+     * OUTERMOST sample loops (level == 0: not inside a path loop) the iterations [ n rank / world, n ( rank + 1 ) / world ),
+     * of the terms under no such loop everything if rank == 0, nothing otherwise.  world <= 1: the whole thing. */
+    uint32_t rank, world;
+    int level;
 } ctx_t;
+static int shard_skips_terms( const ctx_t* c ) { return c->world > 1 && c->level == 0 && c->rank != 0; }
+static int shard_skips_sample( const ctx_t* c, uint64_t j, uint64_t n )
+{
+    if( c->world <= 1 || c->level != 0 ) return 0;
+    return !( j >= n * c->rank / c->world && j < n * ( c->rank + 1 ) / c->world );
+}
 
 #define COUNT( c, k ) do { if( ( c )->cnt ) ( c )->cnt[ k ]++; } while( 0 )
 /* F_alg / T_alg of SURVEY.md App. B: event costs from actinon_amd/csrc/acn_costs.h, tallied at the same places of the
@@ -876,6 +887,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
         double diff_sqr = v3_diff_sqr( pos, v3_ld( enter_obj->pos ) );
         double light_intensity = ( diff_sqr > 0 ) ? ( enter_obj->radiance / diff_sqr ) : F3_MAG;
         COST( c, ACN_F_EMISSION, 0 );
+        if( shard_skips_terms( c ) ) return lum;
         return v3_mlf( obj_color( c->sc, enter_obj, pos ), light_intensity * intensity );
     }
 
@@ -931,7 +943,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
         {
             lum_l = scene_lum( c, &out, a, &trans_l, depth - 1, reflectance * intensity );
         }
-        else
+        else if( !shard_skips_terms( c ) )
         {
             lum_l = v3_mlf( bg, reflectance * intensity );
         }
@@ -953,7 +965,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
         {
             lum_l = scene_lum( c, &out, a, &trans_l, depth - 1, chromatic_reflectivity * intensity );
         }
-        else
+        else if( !shard_skips_terms( c ) )
         {
             lum_l = v3_mlf( bg, chromatic_reflectivity * intensity );
         }
@@ -998,6 +1010,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
                 COUNT( c, ORC_N_CAP_SAMPLE );
                 COST( c, ACN_F_CAP_SAMPLE, ACN_T_CAP_SAMPLE );
                 out.d = m3_mlv( &src_con, v3_random_sphere_cap( &rv, cyl_hgt ) );
+                if( shard_skips_sample( c, j, direct_samples ) ) continue;   /* the draws were made: the stream stays in step */
                 double weight = v3_mlv( out.d, surface.d );
                 if( weight <= 0 ) continue;
 
@@ -1035,6 +1048,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
                 COUNT( c, ORC_N_CAP_SAMPLE );
                 COST( c, ACN_F_CAP_SAMPLE, ACN_T_CAP_SAMPLE );
                 out.d = m3_mlv( &out_con, v3_random_sphere_cap( &rv, 1.0 ) );
+                if( shard_skips_sample( c, i, path_samples ) ) continue;
                 double weight = v3_mlv( out.d, surface.d );
                 if( weight <= 0 ) continue;
                 COST( c, ACN_F_PATH_TAIL, 0 );
@@ -1046,7 +1060,9 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
 
                 if( a < scene->max_path_length )
                 {
+                    c->level++;
                     v3 lum_c = scene_lum( c, &out, a, &trans_l, depth - 10, weight * diffuse_intensity );
+                    c->level--;
                     cl_sum = v3_add( cl_sum, lum_c );
                 }
                 else
@@ -1080,7 +1096,7 @@ static v3 scene_lum( ctx_t* c, const ray_t* ray, double offs, trans_t* trans, ui
         {
             lum_l = scene_lum( c, &out, a, &trans_l, depth - 1, intensity );
         }
-        else
+        else if( !shard_skips_terms( c ) )
         {
             lum_l = v3_mlf( bg, intensity );
         }
@@ -1145,7 +1161,7 @@ static v3 sample_position( ctx_t* c, const camera_t* cam, double monitor_x, doub
     ray.d = m3_mlv( &cam->camera_rotation, d );
     COST( c, ACN_F_CAMERA_RAY, 0 );
 
-    v3 out_clr = v3_ld( s->background_color );
+    v3 out_clr = shard_skips_terms( c ) ? V( 0, 0, 0 ) : v3_ld( s->background_color );
     trans_t trans_l = { { 0, 0, 0 }, -1, -1 };
     double offs = scene_trans_hit( c, &ray, &trans_l );
     if( offs < F3_INF )
@@ -1213,13 +1229,14 @@ typedef struct
     pthread_mutex_t* mutex;
     int linear;
     int count;
+    uint32_t rank, world;
     uint64_t cnt[ ORC_N_COUNTERS ];
 } farm_t;
 
 static void* farm_func( void* arg )
 {
     farm_t* f = arg;
-    ctx_t c = { f->sc, f->count ? f->cnt : NULL };
+    ctx_t c = { f->sc, f->count ? f->cnt : NULL, f->rank, f->world, 0 };
     camera_t cam = camera_setup( &f->sc->params );
     for( ;; )
     {
@@ -1243,6 +1260,13 @@ static void* farm_func( void* arg )
 int acn_oracle_render_positions( const acn_flat_scene* scene, const double* pos_xy, size_t n, double* out_rgb,
                                  uint32_t flags, int threads, uint64_t* counters )
 {
+    return acn_oracle_render_positions_shard( scene, pos_xy, n, out_rgb, flags, threads, counters, 0, 1 );
+}
+
+int acn_oracle_render_positions_shard( const acn_flat_scene* scene, const double* pos_xy, size_t n, double* out_rgb,
+                                       uint32_t flags, int threads, uint64_t* counters, uint32_t rank, uint32_t world )
+{
+    if( world > 1 && ( rank >= world || !( flags & ACN_OPT_LINEAR_OUT ) ) ) return ACN_ERR_ARG;   /* partial sums are linear */
     int st = validate( scene );
     if( st != ACN_OK ) return st;
     if( n && ( !pos_xy || !out_rgb ) ) return ACN_ERR_ARG;
@@ -1259,6 +1283,7 @@ int acn_oracle_render_positions( const acn_flat_scene* scene, const double* pos_
         f->index = &index; f->mutex = &mutex;
         f->linear = ( flags & ACN_OPT_LINEAR_OUT ) != 0;
         f->count = counters != NULL;
+        f->rank = rank; f->world = world;
     }
     if( threads == 1 )
     {

@@ -55,6 +55,11 @@ enum
 int acn_oracle_render_positions( const acn_flat_scene* scene, const double* pos_xy, size_t n, double* out_rgb,
                                  uint32_t flags, int threads, uint64_t* counters );
 
+/* the same for rank `rank` of `world` of a sample-sharded call (ACN_SHARD_SAMPLES, include/actinon_hip.h): linear
+ * partial radiance; the sum over the ranks is the unsharded result up to floating-point reassociation */
+int acn_oracle_render_positions_shard( const acn_flat_scene* scene, const double* pos_xy, size_t n, double* out_rgb,
+                                       uint32_t flags, int threads, uint64_t* counters, uint32_t rank, uint32_t world );
+
 /* obj_estimate_envelope (src/objects.c:312-363): out = pos[3], radius */
 int acn_oracle_estimate_envelope( const acn_flat_scene* scene, int32_t node, uint64_t samples, uint32_t rseed,
                                   double radius_factor, double* out_pos3_radius );

@@ -21,6 +21,7 @@ class Oracle:
         L = self.lib
         vp = C.c_void_p
         L.acn_oracle_render_positions.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint32, C.c_int, vp]
+        L.acn_oracle_render_positions_shard.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint32, C.c_int, vp, C.c_uint32, C.c_uint32]
         L.acn_oracle_estimate_envelope.argtypes = [vp, C.c_int32, C.c_uint64, C.c_uint32, C.c_double, vp]
         L.acn_oracle_sphere_ray_hit.argtypes = [vp, C.c_double, vp, vp, vp]
         L.acn_oracle_sphere_ray_hit.restype = C.c_double
@@ -43,13 +44,15 @@ class Oracle:
     def math_mode(self):
         return self.lib.acn_oracle_math_mode()
 
-    def render_positions(self, flat, pos_xy, linear=False, threads=None, counters=False):
+    def render_positions(self, flat, pos_xy, linear=False, threads=None, counters=False, shard=None):
+        """shard = (rank, world): this rank's share of a sample-sharded call (ACN_SHARD_SAMPLES); linear only."""
         pos = np.ascontiguousarray(pos_xy, dtype=np.float64).reshape(-1, 2)
         out = np.empty((pos.shape[0], 3), dtype=np.float64)
         cnt = (C.c_uint64 * len(COUNTER_NAMES))() if counters else None
         threads = threads or os.cpu_count() or 1
-        st = self.lib.acn_oracle_render_positions(C.addressof(flat.c), pos.ctypes.data, pos.shape[0], out.ctypes.data,
-                                                  1 if linear else 0, threads, cnt)
+        rank, world = shard if shard else (0, 1)
+        st = self.lib.acn_oracle_render_positions_shard(C.addressof(flat.c), pos.ctypes.data, pos.shape[0], out.ctypes.data,
+                                                        1 if linear else 0, threads, cnt, rank, world)
         if st != 0:
             raise RuntimeError(f"oracle status {st}")
         if counters:
