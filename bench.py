@@ -174,16 +174,21 @@ def main():
     n_pix = W * H
     handle = A.Handle(flat, device=local_rank)
 
-    # resident inputs: this rank's pixel positions; accumulators
-    idx_np = adist.rank_pixels(n_pix, rank, world)
+    # resident buffers.  N > 1: the frame is cut into tiles of 256 pixels dealt round-robin to the ranks (acn_shard_tile_*);
+    # a rank renders its tiles into a compact part, the parts are all-gathered over RCCL (every value is copied, none
+    # added: bit-identical to one GPU, 1 / N of the frame sent per rank) and rank 0 interleaves, resolves and copies out
     if args.pixel_stride > 1:
         if world != 1:
             raise SystemExit("--pixel-stride is a single-GPU option")
-        idx_np = idx_np[::args.pixel_stride]
+        idx_np = np.arange(0, n_pix, args.pixel_stride, dtype=np.int64)
         n_pix = idx_np.shape[0]
-    pos = torch.from_numpy(adist.pixel_positions(idx_np, W)).to(dev)
-    idx = torch.from_numpy(idx_np).to(dev)
-    part = torch.empty((idx_np.shape[0], 3), dtype=torch.float64, device=dev)
+        pos = torch.from_numpy(adist.pixel_positions(idx_np, W)).to(dev)
+    else:
+        pos = None
+    n_rank = adist.rank_count(n_pix, rank, world)
+    padded = adist.padded(n_pix, world)
+    part = torch.empty((padded, 3), dtype=torch.float64, device=dev)
+    gathered = torch.empty((world * padded, 3), dtype=torch.float64, device=dev) if world > 1 else None
     frame = torch.zeros((n_pix, 3), dtype=torch.float64, device=dev)
     rgb8 = torch.empty((n_pix, 3), dtype=torch.uint8, device=dev)
     host_img = torch.empty((n_pix, 3), dtype=torch.uint8).pin_memory()
@@ -193,20 +198,22 @@ def main():
 
     def step(record):
         if world > 1:
-            handle.render_positions_dev(pos.data_ptr(), pos.shape[0], part.data_ptr(), linear=True, stream=stream)
-            frame.zero_()
-            frame.index_copy_(0, idx, part)
+            handle.render_main_pass_shard_dev(0, n_pix, rank, world, part.data_ptr(), linear=True, stream=stream)
             if rehearsal:
-                host = frame.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                frame.copy_(host)
+                host = gathered.cpu()
+                dist.all_gather_into_tensor(host, part.cpu())
+                gathered.copy_(host)
             else:
-                dist.all_reduce(frame, op=dist.ReduceOp.SUM)
+                dist.all_gather_into_tensor(gathered, part)
             if rank == 0:
+                handle.shard_unpack_dev(gathered.data_ptr(), n_pix, world, frame.data_ptr(), stream=stream)
                 handle.resolve_dev(frame.data_ptr(), n_pix, None, rgb8.data_ptr(), stream=stream)
                 host_img.copy_(rgb8, non_blocking=True)
         else:
-            handle.render_positions_dev(pos.data_ptr(), pos.shape[0], frame.data_ptr(), linear=True, stream=stream)
+            if pos is None:
+                handle.render_main_pass_dev(0, n_pix, frame.data_ptr(), linear=True, stream=stream)
+            else:
+                handle.render_positions_dev(pos.data_ptr(), pos.shape[0], frame.data_ptr(), linear=True, stream=stream)
             handle.resolve_dev(frame.data_ptr(), n_pix, None, rgb8.data_ptr(), stream=stream)
             host_img.copy_(rgb8, non_blocking=True)
         if record:
@@ -256,7 +263,6 @@ def main():
         value = n_pix * unit * args.steps / elapsed / 1e6
         # algorithmic HBM bytes of one launch of the trace kernel on this rank (DESIGN.md "Roofline"):
         # positions read (16 B) + radiance written (24 B) per pixel + one read of the flattened scene per workgroup
-        n_rank = idx_np.shape[0]
         scene_bytes = flat.n_nodes * 304 + flat.c.n_elems * 4
         workgroups = (n_rank + 63) // 64
         alg_bytes = n_rank * (16 + 24) + workgroups * scene_bytes
@@ -279,8 +285,8 @@ def main():
                                    f"{' at the metric resolution 1920x1080' if args.workload == 'wine_glass_1080p' else ''})"
                        if builder == "wine_glass" else f"{builder} {W}x{H} path_samples={S} direct_samples={int(flat.params.direct_samples)}",
                        "pixels": n_pix, "path_samples": S,
-                       "pixel_subset": (f"every {args.pixel_stride}th pixel of the {W}x{H} raster" if args.pixel_stride > 1 else "all"), "partition": f"pixel tiles of {adist.TILE}, round-robin over {world} rank(s)",
-                       "reduce": "RCCL all_reduce(sum, f64, W*H*3)" if world > 1 else "none"},
+                       "pixel_subset": (f"every {args.pixel_stride}th pixel of the {W}x{H} raster" if args.pixel_stride > 1 else "all"), "partition": f"pixel tiles of {adist.TILE}, round-robin over {world} rank(s) (acn_shard_tile_*)",
+                       "exchange": f"RCCL all_gather of the ranks' parts ({padded * 24} B each), no reduction" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, world),
                          "kernel": "trace pipeline of one main pass (k_trace_rays + k_shade + k_hard_shadow + k_hard_path + k_finalize)",

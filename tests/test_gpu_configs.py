@@ -146,3 +146,60 @@ def test_cancel_flag_inside_the_library(monkeypatch):
         small = h.render_positions(pos[:512], linear=True)
         assert np.isfinite(small).all()
         h.close()
+
+
+def test_sample_shards_sum_to_the_unsharded_render(oracle):
+    """ACN_SHARD_SAMPLES on one GPU: the shares of ranks 0 .. world-1 rendered one after the other add up to the unsharded
+    linear radiance (fixed-point pixel sums: the only difference is where partial sums were rounded to 2^-40), every share
+    equals the oracle's share, and only rank 0 carries the terms under no sample loop."""
+    sc = A.Scene.build("wine_glass", image_width=96, image_height=54, path_samples=64, direct_samples=200)
+    flat = sc.flatten()
+    pos = S.positions(flat)
+    h = A.Handle(flat)
+    full = h.render_positions(pos, linear=True)
+    for world in (2, 8):
+        total = np.zeros_like(full)
+        for rank in range(world):
+            h.sample_shard = (rank, world)
+            part = h.render_positions(pos, linear=True)
+            if world == 2:
+                cpu = oracle.render_positions(flat, pos, linear=True, shard=(rank, world))
+                assert np.abs(part - cpu).max() <= TOL, (rank, np.abs(part - cpu).max())
+            total += part
+        h.sample_shard = None
+        assert np.abs(total - full).max() <= 1e-10, (world, np.abs(total - full).max())
+    # a camera ray that hits nothing is background on rank 0 and nothing on the others
+    sky = np.array([[48.5, 0.5]])
+    h.sample_shard = (0, 2)
+    a = h.render_positions(sky, linear=True)
+    h.sample_shard = (1, 2)
+    b = h.render_positions(sky, linear=True)
+    h.sample_shard = None
+    assert np.allclose(a + b, h.render_positions(sky, linear=True), atol=1e-11)
+    h.close()
+
+
+def test_tile_shards_reassemble_bit_for_bit():
+    """acn_render_main_pass_shard_dev + acn_shard_unpack_dev: the parts of the ranks, gathered rank-major, give the frame of
+    acn_render_main_pass_dev bit for bit (ragged frame: the last tile is short, one rank has a tile less)."""
+    import torch
+    sc = A.Scene.build("wine_glass", image_width=100, image_height=77, path_samples=16, direct_samples=50)
+    flat = sc.flatten()
+    n = 100 * 77
+    h = A.Handle(flat)
+    ref = torch.zeros((n, 3), dtype=torch.float64, device="cuda:0")
+    h.render_main_pass_dev(0, n, ref.data_ptr(), linear=True)
+    for world in (3, 8):
+        padded = A.hip.acn_shard_tile_padded(n, world)
+        gathered = torch.full((world, padded, 3), -1.0, dtype=torch.float64, device="cuda:0")
+        for rank in range(world):
+            h.render_main_pass_shard_dev(0, n, rank, world, gathered[rank].data_ptr(), linear=True)
+        frame = torch.empty((n, 3), dtype=torch.float64, device="cuda:0")
+        h.shard_unpack_dev(gathered.data_ptr(), n, world, frame.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(frame, ref), world
+        # padding rows are zero, never garbage
+        for rank in range(world):
+            cnt = A.hip.acn_shard_tile_count(n, rank, world)
+            assert (gathered[rank, cnt:] == 0).all()
+    h.close()
