@@ -2,7 +2,8 @@
 HIPCC    ?= /opt/rocm/bin/hipcc
 CC       ?= gcc
 ROOT     := $(dir $(abspath $(lastword $(MAKEFILE_LIST))))
-LIBDIR   := actinon_amd/lib
+LIBDIR   ?= actinon_amd/lib
+BUILD    ?= build
 CFLAGS   := -O2 -fPIC -std=gnu11 -Wall -Wno-unused-function -ffp-contract=off -Iinclude
 SHADE_WAVES ?= 4
 WALK_WAVES  ?= 4
@@ -18,9 +19,9 @@ cli: actinon_amd/bin/actinon_hip
 
 # one object per kernel family: `make -j` compiles them side by side (acn_launch.h)
 HIP_UNITS := actinon_hip k_shade_64 k_shade_16 k_shade_4 k_shade_1 k_walk_lds k_walk_glb k_walk_count k_hard_shadow k_hard_path
-HIP_OBJS  := $(addprefix build/,$(addsuffix .o,$(HIP_UNITS)))
-build/%.o: actinon_amd/csrc/%.hip $(wildcard actinon_amd/csrc/*.h) include/actinon_hip.h
-	@mkdir -p build
+HIP_OBJS  := $(addprefix $(BUILD)/,$(addsuffix .o,$(HIP_UNITS)))
+$(BUILD)/%.o: actinon_amd/csrc/%.hip $(wildcard actinon_amd/csrc/*.h) include/actinon_hip.h
+	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 $(LIBDIR)/libactinon_hip.so: $(HIP_OBJS)
 	@mkdir -p $(LIBDIR)

@@ -6,7 +6,8 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBDIR = os.path.join(_HERE, "lib")
+# ACN_LIBDIR: an alternative build of the two libraries (kernel variants under test); default: actinon_amd/lib
+LIBDIR = os.environ.get("ACN_LIBDIR") or os.path.join(_HERE, "lib")
 
 
 def _load(name):

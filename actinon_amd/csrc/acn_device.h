@@ -632,7 +632,7 @@ template< class NP, class CT > DEV int simple_leaf_side_( NP g, V3 pos, CT* cnt 
  * functions below are the reference's obj_side / obj_ray_hit for such operands and pairs, recursion unrolled by L.
  * (Level-1 operands as real function calls instead of in-line expansion: 69.4 vs 57.4 ms on c2 -- calls spill.) */
 template< int L, class SR, class NP, class CT > DEV int pair_side( SR sc, NP n, V3 pos, CT* cnt );
-template< int L, class SR, class NP, class CT > DEV double pair_hit( SR sc, NP n, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt );
+template< int L, bool SPLIT = false, class SR, class NP, class CT > DEV double pair_hit( SR sc, NP n, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt );
 
 template< int L, class SR, class CT > DEV int operand_side( SR sc, int c, V3 pos, CT* cnt )
 {
@@ -692,8 +692,11 @@ template< int L, class SR, class NP, class CT > DEV int pair_side( SR sc, NP n, 
     return operand_side< L >( sc, n->child1, pos, cnt ) == want ? want : -want;
 }
 
-/* the pair's hit without its own envelope test and roughness (the caller does both, as for any node) */
-template< int L, class SR, class NP, class CT > DEV double pair_hit( SR sc, NP n, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
+/* the pair's hit without its own envelope test and roughness (the caller does both, as for any node).
+ * SPLIT: the pair node is the same in every lane (a root element tested by k_shade): the alternating walk then branches on
+ * which operand's turn it is instead of selecting the operand's index per lane -- the operand nodes stay wave-uniform,
+ * i.e. scalar loads from the scalar cache instead of a dozen per-lane vector loads (~1500 cycles each under load) per step. */
+template< int L, bool SPLIT, class SR, class NP, class CT > DEV double pair_hit( SR sc, NP n, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
 {
     int want = ( n->type == ACN_PAIR_INSIDE ) ? -1 : 1;
     int c0 = n->child0, c1 = n->child1;
@@ -710,10 +713,23 @@ template< int L, class SR, class NP, class CT > DEV double pair_hit( SR sc, NP n
     for( ;; )
     {
         V3 walk_p = ray_pos( rp, rd, offs );
-        double a = operand_hit< L >( sc, swapped ? c1 : c0, walk_p, rd, want_nor, &n1, cnt );
-        cnt->cost( ACN_F_PAIR_STEP );
-        if( a >= F3_INF ) return F3_INF;
-        if( operand_side< L >( sc, swapped ? c0 : c1, ray_pos( walk_p, rd, a ), cnt ) == want ) { *nor = n1; return offs + a; }
+        double a;
+        int sd;
+        if constexpr( SPLIT )
+        {
+            if( swapped ) { a = operand_hit< L >( sc, c1, walk_p, rd, want_nor, &n1, cnt ); sd = a < F3_INF ? operand_side< L >( sc, c0, ray_pos( walk_p, rd, a ), cnt ) : 0; }
+            else          { a = operand_hit< L >( sc, c0, walk_p, rd, want_nor, &n1, cnt ); sd = a < F3_INF ? operand_side< L >( sc, c1, ray_pos( walk_p, rd, a ), cnt ) : 0; }
+            cnt->cost( ACN_F_PAIR_STEP );
+            if( a >= F3_INF ) return F3_INF;
+        }
+        else
+        {
+            a = operand_hit< L >( sc, swapped ? c1 : c0, walk_p, rd, want_nor, &n1, cnt );
+            cnt->cost( ACN_F_PAIR_STEP );
+            if( a >= F3_INF ) return F3_INF;
+            sd = operand_side< L >( sc, swapped ? c0 : c1, ray_pos( walk_p, rd, a ), cnt );
+        }
+        if( sd == want ) { *nor = n1; return offs + a; }
         offs += a + 2 * F3_EPS;
         if( !( offs < F3_INF ) ) return F3_INF;
         swapped = !swapped;
@@ -722,6 +738,8 @@ template< int L, class SR, class NP, class CT > DEV double pair_hit( SR sc, NP n
 
 template< class SR, class NP, class CT > DEV int leaf_pair_side( SR sc, NP n, V3 pos, CT* cnt ) { return pair_side< 1 >( sc, n, pos, cnt ); }
 template< class SR, class NP, class CT > DEV double leaf_pair_hit( SR sc, NP n, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt ) { return pair_hit< 1 >( sc, n, rp, rd, want_nor, nor, cnt ); }
+/* the same for a pair node that is the same in every lane */
+template< class SR, class NP, class CT > DEV double leaf_pair_hit_uniform( SR sc, NP n, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt ) { return pair_hit< 1, true >( sc, n, rp, rd, want_nor, nor, cnt ); }
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* CSG machines.  obj_side and obj_ray_hit recurse through pair / neg / scale nodes in the reference; here they are
@@ -1494,7 +1512,7 @@ DEV double leaf_pair_element_hit( const SC& sc, NP n, V3 rp, V3 rd, V3* nor, CT*
     cnt->inc( CNT_OBJ_HIT );
     if( node_has_env( n ) && !env_ray_hits( n, rp, rd ) ) return F3_INF;
     V3 nn = mk( 0, 0, 0 );
-    double a = leaf_pair_hit( sref( sc ), n, rp, rd, NOR, &nn, cnt );
+    double a = leaf_pair_hit_uniform( sref( sc ), n, rp, rd, NOR, &nn, cnt );
     if( NOR && a < F3_INF )
     {
         if( n->surface_roughness > 0 ) nn = roughness_normal( n, nn, ray_pos( rp, rd, a ) );
