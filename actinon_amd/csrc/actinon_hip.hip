@@ -80,7 +80,7 @@ struct Tunables
     uint32_t fetch_walk = 64;          /* ACN_FETCH_WALK: fresh rays a k_walk wave reserves per cursor atomic */
     uint32_t walk_passes = 12;         /* ACN_WALK_PASSES: launches of k_walk per path level (the last one finishes whatever is left) */
     uint32_t private_limit = 32768;    /* ACN_PRIVATE_LIMIT: a generation of at most this many rays is finished on private stacks */
-    uint32_t fetch_shade = 4;          /* ACN_FETCH_SHADE: steps ( of 64 / lanes-per-task tasks ) a k_shade wave reserves per cursor atomic */
+    uint32_t fetch_shade = 16;         /* ACN_FETCH_SHADE: steps ( of 64 / lanes-per-task tasks ) a k_shade wave reserves per cursor atomic */
     uint32_t fetch_hard = 256;         /* ACN_FETCH_HARD: records a wave of the hard-ray kernels / k_shade_hits reserves per atomic */
     uint32_t stack_use = 0;            /* ACN_TEST_STACK_USE: slots of a private stack every walk pass but the last uses (tests of the overflow path) */
     bool     count_work = false;       /* ACN_COUNT_WORK */

@@ -49,18 +49,34 @@ WORKLOADS = {
 }
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+GRID_WORKGROUPS = 1024   # persistent kernels: 4 workgroups of 256 lanes per compute unit (acn_scene_upload)
 FP64_PEAK_TFLOPS = 78.6  # fp64 vector (non-MFMA) peak = half the guide's 157.3 TFLOP/s fp32 vector peak; counts an FMA as 2
 
 
+def kernel_source_hash():
+    """sha256 over the device sources the traffic profile belongs to (csrc/*.h, *.hip)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "actinon_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(workload, world):
-    """HBM bytes per main pass from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 per the gfx950
-    correction + WRITE_SIZE, KB -> bytes), for the same workload on one GPU; None if no such profile exists."""
+    """HBM bytes per main pass from the rocprofv3 PMC passes committed under profiles/ (scripts/pmc_traffic.sh: FETCH_SIZE x2
+    per the gfx950 correction + WRITE_SIZE, KB -> bytes, separate passes) for the same workload on one GPU -- but only if
+    that profile was taken on THESE kernels (it is stamped with kernel_source_hash()); else None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if world != 1 or not os.path.exists(path):
         return None
     try:
-        t = json.load(open(path))
-        return t.get(workload, {}).get("hbm_bytes_per_step")
+        t = json.load(open(path)).get(workload, {})
+        if t.get("kernel_source_hash") != kernel_source_hash():
+            return None
+        return t.get("hbm_bytes_per_step")
     except (OSError, ValueError):
         return None
 
@@ -261,11 +277,11 @@ def main():
     if rank == 0:
         unit = max(S, 1)
         value = n_pix * unit * args.steps / elapsed / 1e6
-        # algorithmic HBM bytes of one launch of the trace kernel on this rank (DESIGN.md "Roofline"):
-        # positions read (16 B) + radiance written (24 B) per pixel + one read of the flattened scene per workgroup
-        scene_bytes = flat.n_nodes * 304 + flat.c.n_elems * 4
-        workgroups = (n_rank + 63) // 64
-        alg_bytes = n_rank * (16 + 24) + workgroups * scene_bytes
+        # algorithmic HBM bytes of one main pass on this rank: the radiance written (24 B per
+        # position; positions are generated on the device) + one read of the flattened scene per workgroup that runs
+        scene_bytes = flat.n_nodes * 288 + flat.c.n_elems * 8      # GNode 192 B + GMat 96 B per node, elems twice
+        workgroups = int(stages["walk_launches"] + stages["shade_launches"] + stages["hard_launches"]) * GRID_WORKGROUPS
+        alg_bytes = n_rank * 24 + workgroups * scene_bytes
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "Msamples/s (pixels x path_samples), one main pass" if S else "Mpixels/s (path_samples = 0), one main pass",
@@ -289,8 +305,13 @@ def main():
                        "exchange": f"RCCL all_gather of the ranks' parts ({padded * 24} B each), no reduction" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, world),
-                         "kernel": "trace pipeline of one main pass (k_trace_rays + k_shade + k_hard_shadow + k_hard_path + k_finalize)",
+                         "kernel": "all kernels of one main pass (k_walk passes, k_shade x 4 size classes, k_hard_shadow, k_hard_path, "
+                                   "k_shade_hits, k_finalize), HIP events on the launch stream around the pass; with concurrent "
+                                   "lanes the per-family sums below overlap and exceed it",
                          "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
+                         "family_ms_summed_over_lanes": {"k_walk+k_shade_hits": stages["walk_ms"], "k_shade": stages["shade_ms"],
+                                                         "k_hard_*": stages["hard_ms"], "k_finalize": stages["finalize_ms"]},
+                         "traffic_profile": "profiles/traffic.json (stamped with the kernel source hash; null when stale)",
                          "note": "the path is fp64-VALU-issue bound with divergent CSG traversal; the HBM roofline is "
                                  "reported because BASELINE.json asks for it (DESIGN.md 7)"},
             "roofline_fp64": None if counters is None else {
