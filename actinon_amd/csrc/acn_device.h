@@ -118,6 +118,18 @@ extern __shared__ __attribute__( ( aligned( 16 ) ) ) double acn_lds_raw[];
 #define ACN_LDS_STACK_BYTES ( ACN_LDS_DEPTH * ACN_LDS_LANES * 40 )
 #define ACN_NO_LDS_STACK 0xFFFFFFFFu
 
+/* One entry of a simple compound's pre-order table (simple_compound_hit): everything a visit needs -- the element's
+ * envelope, its type and the two links -- in ONE 48-byte record, i.e. one memory round trip per visited node instead
+ * of three dependent ones (element index -> node header -> envelope). */
+struct SCEntry
+{
+    double  env_pos[ 3 ], env_radius;
+    int32_t node;        /* node index (leaves: the object that is hit) */
+    int32_t skip;        /* entry behind this element's subtree */
+    int32_t type;        /* acn_node_type */
+    uint32_t flags;      /* ACN_NODE_HAS_ENVELOPE */
+};
+
 /* device-resident scene, parameterised by where the node array is read from */
 template< class NP >
 struct DevSceneT
@@ -135,6 +147,7 @@ struct DevSceneT
     uint32_t* flags;     /* device word for ACN_FLAG_* error bits */
     uint32_t lds_stack;  /* byte offset of the CSG stack area in dynamic LDS, ACN_NO_LDS_STACK if the kernel has none */
     uint32_t prune_base; /* elems[ prune_base + node ]: offset of the node's prune program in elems[], or -1 */
+    const SCEntry* sc_table;   /* pre-order tables of the simple compounds */
     static constexpr bool prune = false;
 };
 /* the same scene for the "extras" kernel variants: interval-prune programs and in-line simple compounds.  Launched
@@ -149,7 +162,7 @@ __device__ __forceinline__ DevSceneT< NP2 > scene_rebind( const DevScene& sc, NP
     DevSceneT< NP2 > r;
     r.nodes = nodes; r.mats = sc.mats; r.elems = sc.elems; r.textures = sc.textures;
     r.light_root = sc.light_root; r.matter_root = sc.matter_root; r.n_nodes = sc.n_nodes; r.n_elems = sc.n_elems;
-    r.prm = sc.prm; r.camera_rotation = sc.camera_rotation; r.unit_f = sc.unit_f; r.flags = sc.flags; r.lds_stack = sc.lds_stack; r.prune_base = sc.prune_base;
+    r.prm = sc.prm; r.camera_rotation = sc.camera_rotation; r.unit_f = sc.unit_f; r.flags = sc.flags; r.lds_stack = sc.lds_stack; r.prune_base = sc.prune_base; r.sc_table = sc.sc_table;
     return r;
 }
 
@@ -437,6 +450,18 @@ template< class NP > DEV M3 node_rax( NP n )
 /* envelope_s_ray_hits (objects.c:90-93) = sphere_ray_hit( ... ) < f3_inf.  Only the predicate is needed: by
  * gmath.h:64-83 the offset is finite exactly when s*s >= q and ( s < 0 or q < 0 ) -- the square root of the
  * non-negative discriminant is finite for finite inputs -- so the sqrt is not evaluated. */
+template< class NP, class CT > DEV bool env_ray_hits_( NP n, V3 rp, V3 rd, CT* cnt );
+/* the same on an envelope given by value */
+template< class CT > DEV bool env_ray_hits_raw( V3 env_pos, double r, V3 rp, V3 rd, CT* cnt )
+{
+    V3 p = v_sub( rp, env_pos );
+    double s = v_mlv( p, rd );
+    double q = v_sqr( p ) - ( r * r );
+    double s2 = s * s;
+    bool hit = !( s2 < q ) && ( ( s < 0 && q > 0 ) || ( s < 0 || q < 0 ) );
+    cnt->cost( hit ? ACN_F_ENV_HIT : ACN_F_ENV_MISS );
+    return hit;
+}
 template< class NP, class CT > DEV bool env_ray_hits_( NP n, V3 rp, V3 rd, CT* cnt )
 {
     V3 p = v_sub( rp, ld3( n->env_pos ) );
@@ -1139,8 +1164,8 @@ DEVN double compound_ray_hit_dev( SR sc, int cmp, V3 rp, V3 rd, bool want_nor, V
 
 /* Simple compounds: a root element that is a compound whose whole subtree consists of nested compounds and simple
  * leaves (many_spheres: 32 768 spheres under five levels of enveloped compounds).  The upload step lays its subtree
- * out in pre-order with a skip link per entry ( node, index of the entry behind the subtree ), elems[ offset ] holding
- * the entry count; compound_s_ray_hit (compound.c:215-243) then is a stackless loop: an enveloped compound that the
+ * out in pre-order as SCEntry records with a skip link per entry (elems[ offset ], elems[ offset + 1 ]: first entry and
+ * entry count); compound_s_ray_hit (compound.c:215-243) then is a stackless loop: an enveloped compound that the
  * ray misses is skipped by its link, everything else advances by one.  Same element order as the recursion, so ties
  * between equal distances resolve identically.  No stack, no machine: k_shade runs it in line. */
 #define ACN_GFLAG_SIMPLE_COMPOUND 0x200u   /* device-only bit of GNode.flags */
@@ -1148,29 +1173,28 @@ DEVN double compound_ray_hit_dev( SR sc, int cmp, V3 rp, V3 rd, bool want_nor, V
 template< bool NOR, class SC, class CT >
 DEV double simple_compound_hit( const SC& sc, int cmp, V3 rp, V3 rd, V3* p_nor, int* hit_obj, double limit, CT* cnt )
 {
-    int base = sc.elems[ sc.prune_base + ( uint32_t )cmp ];
-    int count = sc.elems[ base ];
-    int i = base + 1, end = base + 1 + 2 * count;
+    int off = sc.elems[ sc.prune_base + ( uint32_t )cmp ];
+    int i = sc.elems[ off ], end = i + sc.elems[ off + 1 ];
     double min_a = F3_INF;
     while( i < end )
     {
-        int node = sc.elems[ i ];
-        auto e = &sc.nodes[ node ];
-        if( e->type == ACN_COMPOUND )
+        const SCEntry e = sc.sc_table[ i ];
+        const bool miss = ( e.flags & ACN_NODE_HAS_ENVELOPE ) && !env_ray_hits_raw( ld3( e.env_pos ), e.env_radius, rp, rd, cnt );
+        if( e.type == ACN_COMPOUND )
         {
-            i = ( node_has_env( e ) && !env_ray_hits( e, rp, rd ) ) ? sc.elems[ i + 1 ] : i + 2;
+            i = miss ? e.skip : i + 1;
             continue;
         }
-        i += 2;
+        i++;
         cnt->inc( CNT_OBJ_HIT );
-        if( node_has_env( e ) && !env_ray_hits( e, rp, rd ) ) continue;
+        if( miss ) continue;
         V3 nor = mk( 0, 0, 0 );
-        double a = simple_leaf_hit( e, rp, rd, NOR, &nor );
+        double a = simple_leaf_hit( &sc.nodes[ e.node ], rp, rd, NOR, &nor );
         if( a < min_a )
         {
             min_a = a;
             if( NOR ) *p_nor = nor;
-            *hit_obj = node;
+            *hit_obj = e.node;
             if( a <= limit ) return a;
         }
     }

@@ -134,6 +134,7 @@ struct acn_scene_handle
     GMat*    d_mats = nullptr;
     int32_t* d_elems = nullptr;
     acn_texture* d_textures = nullptr;
+    SCEntry* d_sc_table = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -516,6 +517,7 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
      * test cost (any-hit occlusion queries are an OR over the elements, so their order is free; closest-hit queries
      * keep the given order because ties go to the first element, compound.c:225-243) */
     std::vector< int32_t > elems2( 2 * ( size_t )scene->n_elems + 1, 0 );
+    std::vector< SCEntry > sc_table;   /* pre-order tables of the simple compounds (acn_device.h: simple_compound_hit) */
     {
         std::vector< double > cost( scene->n_nodes, -1.0 );
         std::function< double( int32_t ) > node_cost = [ & ]( int32_t i ) -> double
@@ -654,6 +656,7 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
          * are compounds over nothing but compounds and simple leaves; the same per-node offset table locates them */
         if( !getenv( "ACN_NO_SIMPLE_COMPOUNDS" ) )
         {
+            std::vector< SCEntry >& sct = sc_table;
             std::vector< int8_t > simple( scene->n_nodes, -1 );
             std::function< bool( int32_t ) > is_simple = [ & ]( int32_t i ) -> bool
             {
@@ -674,11 +677,14 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
                 for( int32_t k = 0; k < a.child1; k++ )
                 {
                     int32_t e = scene->elems[ a.child0 + k ];
-                    size_t at = elems2.size();
-                    elems2.push_back( e );
-                    elems2.push_back( 0 );
-                    if( scene->nodes[ e ].type == ACN_COMPOUND ) emit( e );
-                    elems2[ at + 1 ] = ( int32_t )elems2.size();   /* the entry behind e's subtree */
+                    const acn_node& en = scene->nodes[ e ];
+                    size_t at = sct.size();
+                    SCEntry rec;
+                    memcpy( rec.env_pos, en.env_pos, sizeof( rec.env_pos ) );
+                    rec.env_radius = en.env_radius; rec.node = e; rec.skip = 0; rec.type = en.type; rec.flags = en.flags & ACN_NODE_HAS_ENVELOPE;
+                    sct.push_back( rec );
+                    if( en.type == ACN_COMPOUND ) emit( e );
+                    sct[ at ].skip = ( int32_t )sct.size();   /* the entry behind e's subtree */
                 }
             };
             for( int root : { scene->light_root, scene->matter_root } )
@@ -688,11 +694,11 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
                 {
                     int32_t e = scene->elems[ r.child0 + k ];
                     if( scene->nodes[ e ].type != ACN_COMPOUND || !is_simple( e ) || elems2[ h->dev.prune_base + e ] >= 0 ) continue;
-                    size_t at = elems2.size();
-                    elems2[ h->dev.prune_base + e ] = ( int32_t )at;
-                    elems2.push_back( 0 );
+                    elems2[ h->dev.prune_base + e ] = ( int32_t )elems2.size();
+                    elems2.push_back( ( int32_t )sct.size() );     /* first entry */
+                    size_t first = sct.size();
                     emit( e );
-                    elems2[ at ] = ( int32_t )( ( elems2.size() - at - 1 ) / 2 );
+                    elems2.push_back( ( int32_t )( sct.size() - first ) );   /* entry count */
                     nodes[ e ].flags |= ACN_GFLAG_SIMPLE_COMPOUND;
                     h->prune = true;   /* the extras kernel variants */
                 }
@@ -702,6 +708,9 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     }
     h->scene_bytes[ 2 ] = sizeof( int32_t ) * elems2.size();
     HIP_TRY_H( hipMalloc( &h->d_elems, sizeof( int32_t ) * elems2.size() ) );
+    HIP_TRY_H( hipMalloc( &h->d_sc_table, sizeof( SCEntry ) * ( sc_table.size() ? sc_table.size() : 1 ) ) );
+    if( sc_table.size() ) HIP_TRY_H( hipMemcpy( h->d_sc_table, sc_table.data(), sizeof( SCEntry ) * sc_table.size(), hipMemcpyHostToDevice ) );
+    h->dev.sc_table = h->d_sc_table;
     HIP_TRY_H( hipMalloc( &h->d_textures, sizeof( acn_texture ) * ( scene->n_textures ? scene->n_textures : 1 ) ) );
     if( scene->n_textures ) HIP_TRY_H( hipMemcpy( h->d_textures, scene->textures, sizeof( acn_texture ) * scene->n_textures, hipMemcpyHostToDevice ) );
     HIP_TRY_H( hipMalloc( &h->d_counters, sizeof( unsigned long long ) * ( CNT_N + 2 ) ) );
@@ -794,6 +803,7 @@ extern "C" void acn_scene_free( acn_scene_handle* h )
         if( h->d_mats ) hipFree( h->d_mats );
         if( h->d_elems ) hipFree( h->d_elems );
         if( h->d_textures ) hipFree( h->d_textures );
+        if( h->d_sc_table ) hipFree( h->d_sc_table );
     }
     if( h->d_counters ) hipFree( h->d_counters );
     for( auto& e : h->events ) { hipEventDestroy( e.a ); hipEventDestroy( e.b ); }
