@@ -203,6 +203,52 @@ template<> struct Cnt< false >
  * of the reference's algorithm, call the underscore forms with ACN_NO_CNT) */
 #define ACN_NO_CNT ( ( Cnt< false >* )nullptr )
 
+/* Phase timers (diagnostic builds only: make ... EXTRA=-DACN_PHASE_TIMERS).  Every wave keeps a time stamp and ACN_PH_N
+ * accumulators in LDS; ACN_LAP( k ) books the shader-clock time since the wave's previous mark on phase k, whichever
+ * lanes are active.  phase_flush adds the wave's sums to counters[ CNT_N + 2 + 16 * kernel + k ] at kernel end. */
+#define ACN_PH_N 16
+#define ACN_PH_KERNELS 3
+#define ACN_CNT_SLOTS ( CNT_N + 2 + ACN_PH_N * ACN_PH_KERNELS )
+enum { PH_OTHER = 0, PH_LIGHT, PH_ROOT_LEAF, PH_PRUNE, PH_M_LEAF, PH_M_PAIR, PH_M_FRAME, PH_M_SIDE, PH_SHADE, PH_COMPOUND, PH_FETCH, PH_TAIL };
+#ifdef ACN_PHASE_TIMERS
+__shared__ unsigned long long acn_phase_lds[ 4 ][ ACN_PH_N + 1 ];
+__device__ __forceinline__ void phase_lap( int k )
+{
+    unsigned long long now = __builtin_readcyclecounter();
+    unsigned long long ex = __ballot( 1 );
+    if( ( int )( threadIdx.x & 63 ) == __ffsll( ( long long )ex ) - 1 )
+    {
+        unsigned long long* w = acn_phase_lds[ threadIdx.x >> 6 ];
+        w[ 1 + k ] += now - w[ 0 ];
+        w[ 0 ] = now;
+    }
+}
+__device__ __forceinline__ void phase_init()
+{
+    if( ( threadIdx.x & 63 ) == 0 )
+    {
+        unsigned long long* w = acn_phase_lds[ threadIdx.x >> 6 ];
+        for( int k = 1; k <= ACN_PH_N; k++ ) w[ k ] = 0;
+        w[ 0 ] = __builtin_readcyclecounter();
+    }
+}
+__device__ __forceinline__ void phase_flush( unsigned long long* counters, int kernel )
+{
+    if( ( threadIdx.x & 63 ) == 0 )
+    {
+        unsigned long long* w = acn_phase_lds[ threadIdx.x >> 6 ];
+        for( int k = 0; k < ACN_PH_N; k++ ) if( w[ 1 + k ] ) atomicAdd( &counters[ CNT_N + 2 + ACN_PH_N * kernel + k ], w[ 1 + k ] );
+    }
+}
+#define ACN_LAP( k ) phase_lap( k )
+#define ACN_PHASE_INIT phase_init();
+#define ACN_PHASE_FLUSH( counters, kernel ) phase_flush( counters, kernel );
+#else
+#define ACN_LAP( k )
+#define ACN_PHASE_INIT
+#define ACN_PHASE_FLUSH( counters, kernel )
+#endif
+
 /* the two read-only scene arrays, passed BY VALUE into the non-inlined machines (global address space, so the
  * scene struct is never forced into scratch) */
 template< class NP > struct SceneRefT { NP nodes; ElemP elems; uint32_t* flags; uint32_t n_elems; uint32_t lds_stack; };
@@ -793,6 +839,7 @@ DEV_SIDE int obj_side_dev( SR sc, int root, V3 pos, CT* cnt )
     int depth = 0, na = 0;
     int node = root;
     int r = 1;
+    ACN_LAP( PH_M_FRAME );
     for( ;; )
     {
         /* EVAL( node, pos ) */
@@ -849,7 +896,7 @@ DEV_SIDE int obj_side_dev( SR sc, int root, V3 pos, CT* cnt )
         /* RETURN( r ) into the enclosing composites */
         while( have )
         {
-            if( depth == 0 ) return r;
+            if( depth == 0 ) { ACN_LAP( PH_M_SIDE ); return r; }
             int cnode = ( int )( cur >> 2 );
             auto fn = &sc.nodes[ cnode ];
             int ftype = fn->type;
@@ -910,6 +957,7 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
     for( ;; )
     {
         /* ---- EVAL( node, rp, rd ) ---- */
+        ACN_LAP( PH_M_FRAME );
         auto n = &sc.nodes[ node ];
         cnt->inc( CNT_OBJ_HIT );
         bool have = true;
@@ -928,12 +976,14 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
                 default:           ret_a = distance_ray_hit( n, rp, rd, want_nor, &ret_n, cnt ); break;
             }
             if( want_nor && ret_a < F3_INF && n->surface_roughness > 0 ) ret_n = roughness_normal( n, ret_n, ray_pos( rp, rd, ret_a ) );
+            ACN_LAP( PH_M_LEAF );
         }
         else if( n->flags & ( ACN_GFLAG_LEAF_PAIR | ACN_GFLAG_PAIR2 ) )
         {
             ret_a = ( n->flags & ACN_GFLAG_PAIR2 ) ? pair_hit< 2 >( sc, n, rp, rd, want_nor, &ret_n, cnt )
                                                    : pair_hit< 1 >( sc, n, rp, rd, want_nor, &ret_n, cnt );
             if( want_nor && ret_a < F3_INF && n->surface_roughness > 0 ) ret_n = roughness_normal( n, ret_n, ray_pos( rp, rd, ret_a ) );
+            ACN_LAP( PH_M_PAIR );
         }
         else if( depth >= ACN_CSG_MAX_DEPTH )
         {
@@ -986,6 +1036,7 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
             {
                 /* like the reference, the caller's normal is only written on a hit (obj_ray_exit relies on it) */
                 if( want_nor && ret_a < F3_INF ) *out_nor = ret_n;
+                ACN_LAP( PH_M_FRAME );
                 return ret_a;
             }
             int cnode = ACN_HW_NODE( cur_w );
@@ -1411,7 +1462,10 @@ DEV double element_hit( const SC& sc, int e, V3 rp, V3 rd, V3* nor, int* hit_obj
                 return simple_compound_hit< NOR >( sc, e, rp, rd, nor, hit_obj, limit, cnt );
             }
         }
-        return compound_ray_hit_dev( sref( sc ), e, rp, rd, NOR, nor, hit_obj, limit, cnt );
+        ACN_LAP( PH_ROOT_LEAF );
+        double ac = compound_ray_hit_dev( sref( sc ), e, rp, rd, NOR, nor, hit_obj, limit, cnt );
+        ACN_LAP( PH_COMPOUND );
+        return ac;
     }
     *hit_obj = e;
     bool env = node_has_env( n );
@@ -1428,7 +1482,9 @@ DEV double element_hit( const SC& sc, int e, V3 rp, V3 rd, V3* nor, int* hit_obj
             return aa;
         }
 #endif
-        if( type != ACN_DISTANCE && ( surely_outside< ACN_PRUNE_DEPTH >( sc, e, rp, rd ) || prune_run( sc, e, rp, rd, F3_INF ) ) ) { cnt->inc( CNT_OBJ_HIT ); return F3_INF; }
+        ACN_LAP( PH_ROOT_LEAF );
+        if( type != ACN_DISTANCE && ( surely_outside< ACN_PRUNE_DEPTH >( sc, e, rp, rd ) || prune_run( sc, e, rp, rd, F3_INF ) ) ) { cnt->inc( CNT_OBJ_HIT ); ACN_LAP( PH_PRUNE ); return F3_INF; }
+        ACN_LAP( PH_PRUNE );
         return obj_ray_hit_dev( sref( sc ), e, rp, rd, NOR, nor, cnt );   /* the machine redoes the envelope test */
     }
     cnt->inc( CNT_OBJ_HIT );
@@ -1653,16 +1709,19 @@ DEV double scene_trans_hit_dev( const SC& sc, V3 rp, V3 rd, Trans* trans, CT* cn
     double a;
     Trans trans_l;
     trans_l.exit_nor = mk( 0, 0, 0 ); trans_l.exit_obj = -1; trans_l.enter_obj = -1;
+    ACN_LAP( PH_FETCH );
     if( ( a = root_trans_hit( sc, sc.light_root, rp, rd, &trans_l, cnt ) ) < min_a )
     {
         min_a = a;
         *trans = trans_l;
     }
+    ACN_LAP( PH_LIGHT );
     if( ( a = root_trans_hit( sc, sc.matter_root, rp, rd, &trans_l, cnt ) ) < min_a )
     {
         min_a = a;
         *trans = trans_l;
     }
+    ACN_LAP( PH_ROOT_LEAF );
     return min_a;
 }
 

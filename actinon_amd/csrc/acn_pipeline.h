@@ -617,6 +617,7 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
     if constexpr( LDS ) ACN_STAGE_NODES( sc )
     const ChunkP cs = ACN_CHUNKS_OF_WAVE;
     chunks_init( cs );
+    ACN_PHASE_INIT
     Cnt< COUNT > cnt;
     cnt.clear();
     const int lane = ( int )( threadIdx.x & 63 );
@@ -694,7 +695,10 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
         /* the wave reads next what it wrote last: same wave, program order; the fence keeps the compiler from moving the
          * next step's loads above this step's stores */
         __builtin_amdgcn_fence( __ATOMIC_SEQ_CST, "wavefront" );
+        ACN_LAP( PH_SHADE );
     }
+    ACN_LAP( PH_TAIL );
+    ACN_PHASE_FLUSH( counters, 0 )
     /* the step bound is a safety net against a loop that does not end; work would be lost, so the call fails */
     if( !finished && lane == 0 ) atomicOr( p_counts + QC_FLAGS, ACN_FLAG_STACK_OVERFLOW );
     sink.out.close();
@@ -714,15 +718,16 @@ void k_shade_hits( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const HitRec* __restrict_
                    unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_CHUNK_STATES
+    uint32_t n = *n_ptr;
+    n = n < rec_cap ? n : rec_cap;
+    n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
+    if( n == 0 ) return;
     ACN_SCENE_VIEW
     ACN_TASKQ_VIEW
     const ChunkP cs = ACN_CHUNKS_OF_WAVE;
     chunks_init( cs );
     Cnt< COUNT > cnt;
     cnt.clear();
-    uint32_t n = *n_ptr;
-    n = n < rec_cap ? n : rec_cap;
-    n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
     RayQ rq;
     rq.rays = rays_out; rq.counter = p_counts + QC_GEN; rq.cap = ray_cap; rq.flags = p_counts + QC_FLAGS; rq.cs = cs + 5;
     FetchRange fr;
@@ -996,6 +1001,7 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
     Cnt< COUNT > cnt;
     cnt.clear();
     if constexpr( LDS ) ACN_STAGE_NODES( sc )
+    ACN_PHASE_INIT
     uint32_t n = p_counts[ QC_HARD_SHADOW ];
     n = n < cap ? n : cap;
     n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
@@ -1012,12 +1018,17 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
             if( r.pixel != ACN_INVALID )
             {
                 bool occ;
+                ACN_LAP( PH_FETCH );
                 if constexpr( LDS ) occ = root_occluded( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, r.limit, &cnt );
                 else                occ = root_occluded( scene_view< PRUNE >( sc, sc.nodes ), sc.matter_root, r.pos, r.d, r.limit, &cnt );
+                ACN_LAP( PH_ROOT_LEAF );
                 if( !occ ) { cnt.cost( ACN_F_DIRECT_TAIL ); pixel_add( accum, sc.flags, r.pixel, r.contrib ); }
+                ACN_LAP( PH_SHADE );
             }
         }
     }
+    ACN_LAP( PH_TAIL );
+    ACN_PHASE_FLUSH( counters, 1 )
     wave_add_counters( counters, cnt );
 }
 
@@ -1033,6 +1044,7 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
     Cnt< COUNT > cnt;
     cnt.clear();
     if constexpr( LDS ) ACN_STAGE_NODES( sc )
+    ACN_PHASE_INIT
     const ChunkP cs = ACN_CHUNKS_OF_WAVE;
     chunks_init( cs );
     uint32_t n = p_counts[ QC_HARD_PATH ];
@@ -1056,8 +1068,10 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
         if( ( threadIdx.x & 63 ) < got ) r = recs[ first + ( threadIdx.x & 63 ) ];
         if( r.pixel != ACN_INVALID )
         {
+            ACN_LAP( PH_FETCH );
             if constexpr( LDS ) a = root_trans_hit( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, &trans, &cnt );
             else                a = root_trans_hit( scene_view< PRUNE >( sc, sc.nodes ), sc.matter_root, r.pos, r.d, &trans, &cnt );
+            ACN_LAP( PH_ROOT_LEAF );
             hit = a < sc.prm.max_path_length;
             if( !hit )
             {
@@ -1083,6 +1097,8 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
             }
         }
     }
+    ACN_LAP( PH_SHADE );
+    ACN_PHASE_FLUSH( counters, 2 )
     chunk_close( cs + 0, child_cap, kill_ch );
     wave_stat_add( p_counts + QS_CHILDREN, n_ch );
     wave_add_counters( counters, cnt );

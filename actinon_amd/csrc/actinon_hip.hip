@@ -713,8 +713,8 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     h->dev.sc_table = h->d_sc_table;
     HIP_TRY_H( hipMalloc( &h->d_textures, sizeof( acn_texture ) * ( scene->n_textures ? scene->n_textures : 1 ) ) );
     if( scene->n_textures ) HIP_TRY_H( hipMemcpy( h->d_textures, scene->textures, sizeof( acn_texture ) * scene->n_textures, hipMemcpyHostToDevice ) );
-    HIP_TRY_H( hipMalloc( &h->d_counters, sizeof( unsigned long long ) * ( CNT_N + 2 ) ) );
-    HIP_TRY_H( hipMemset( h->d_counters, 0, sizeof( unsigned long long ) * ( CNT_N + 2 ) ) );
+    HIP_TRY_H( hipMalloc( &h->d_counters, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
+    HIP_TRY_H( hipMemset( h->d_counters, 0, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
     HIP_TRY_H( hipMalloc( &h->d_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
     HIP_TRY_H( hipHostMalloc( &h->h_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
     HIP_TRY_H( hipMemcpy( h->d_nodes, nodes.data(), sizeof( GNode ) * scene->n_nodes, hipMemcpyHostToDevice ) );
@@ -1032,7 +1032,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     h->hard_rays = 0; h->walk_steps = 0; h->walk_rays = 0; h->shade_hit_recs = 0; h->host_syncs = 0; h->flags_seen = 0; h->private_rays = 0;
     h->chunks = h->retries = h->levels = 0;
     h->peak_tasks = h->peak_children = 0;
-    HIP_TRY( hipMemsetAsync( h->d_counters, 0, sizeof( unsigned long long ) * ( CNT_N + 2 ), stream ) );
+    HIP_TRY( hipMemsetAsync( h->d_counters, 0, sizeof( unsigned long long ) * ACN_CNT_SLOTS, stream ) );
     HIP_TRY( hipEventRecord( h->ev0, stream ) );
     HIP_TRY( hipMemsetAsync( h->d_accum, 0, sizeof( unsigned long long ) * 3 * n, stream ) );
 
@@ -1175,8 +1175,8 @@ static int make_lane( acn_scene_handle* parent, int lanes, acn_scene_handle** ou
     HIP_TRY_L( hipStreamCreateWithFlags( &l->stream, hipStreamNonBlocking ) );
     HIP_TRY_L( hipEventCreate( &l->ev0 ) );
     HIP_TRY_L( hipEventCreate( &l->ev1 ) );
-    HIP_TRY_L( hipMalloc( &l->d_counters, sizeof( unsigned long long ) * ( CNT_N + 2 ) ) );
-    HIP_TRY_L( hipMemset( l->d_counters, 0, sizeof( unsigned long long ) * ( CNT_N + 2 ) ) );
+    HIP_TRY_L( hipMalloc( &l->d_counters, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
+    HIP_TRY_L( hipMemset( l->d_counters, 0, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
     HIP_TRY_L( hipMalloc( &l->d_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
     HIP_TRY_L( hipMemset( l->d_counts, 0, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
     HIP_TRY_L( hipHostMalloc( &l->h_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
@@ -1223,7 +1223,7 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
             auto run = [ & ]() -> int
             {
                 HIP_TRY( hipSetDevice( h->device ) );
-                if( cnt == 0 ) { l->events_used = 0; HIP_TRY( hipMemset( l->d_counters, 0, sizeof( unsigned long long ) * ( CNT_N + 2 ) ) ); return ACN_OK; }
+                if( cnt == 0 ) { l->events_used = 0; HIP_TRY( hipMemset( l->d_counters, 0, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) ); return ACN_OK; }
                 if( l->lane_buf_cap < cnt )
                 {
                     if( l->d_lane_pos ) hipFree( l->d_lane_pos );
@@ -1457,18 +1457,18 @@ extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
 
 extern "C" int acn_last_counters( acn_scene_handle* h, uint64_t* out, int n )
 {
-    if( !h || !out || n < 0 || n > 16 ) return fail( ACN_ERR_ARG, "bad argument" );
+    if( !h || !out || n < 0 || n > 64 ) return fail( ACN_ERR_ARG, "bad argument" );
     HIP_TRY( hipSetDevice( h->device ) );
-    unsigned long long c[ CNT_N + 2 ], sum[ CNT_N + 2 ];
-    for( int k = 0; k < CNT_N + 2; k++ ) sum[ k ] = 0;
+    unsigned long long c[ ACN_CNT_SLOTS ], sum[ ACN_CNT_SLOTS ];
+    for( int k = 0; k < ACN_CNT_SLOTS; k++ ) sum[ k ] = 0;
     std::vector< const acn_scene_handle* > src{ h };
     if( h->used_lanes ) src.assign( h->lanes.begin(), h->lanes.end() );
     for( const acn_scene_handle* l : src )
     {
         HIP_TRY( hipMemcpy( c, l->d_counters, sizeof( c ), hipMemcpyDeviceToHost ) );
-        for( int k = 0; k < CNT_N + 2; k++ ) sum[ k ] += c[ k ];
+        for( int k = 0; k < ACN_CNT_SLOTS; k++ ) sum[ k ] += c[ k ];
     }
-    for( int k = 0; k < n; k++ ) out[ k ] = k < CNT_N + 2 ? sum[ k ] : 0;
+    for( int k = 0; k < n; k++ ) out[ k ] = k < ACN_CNT_SLOTS ? sum[ k ] : 0;
     return ACN_OK;
 }
 

@@ -296,6 +296,18 @@ class Handle:
         check(hip.acn_last_counters(self.h, buf, 10), "acn_last_counters")
         return dict(zip(names, [int(v) for v in buf]))
 
+    PHASES = ["other", "light", "root_leaf", "prune", "m_leaf", "m_pair", "m_frame", "m_side", "shade", "compound", "fetch",
+              "tail"]
+
+    def last_phase_ticks(self):
+        """{kernel: {phase: shader-clock ticks}} of a library built with -DACN_PHASE_TIMERS (all zero otherwise)"""
+        buf = (C.c_uint64 * 58)()
+        check(hip.acn_last_counters(self.h, buf, 58), "acn_last_counters")
+        out = {}
+        for k, kernel in enumerate(["walk", "hard_shadow", "hard_path"]):
+            out[kernel] = {p: int(buf[10 + 16 * k + i]) for i, p in enumerate(self.PHASES)}
+        return out
+
     def estimate_envelope(self, node, samples=1000, rseed=123, radius_factor=1.1):
         out = (C.c_double * 4)()
         check(hip.acn_estimate_envelope(self.h, node, samples, rseed, radius_factor, out), "acn_estimate_envelope")

@@ -257,7 +257,10 @@ int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms );
  * stacks instead of in generation passes. n <= 22. */
 int acn_last_stage_ms( acn_scene_handle* h, double* out, int n );
 
-/* Work counters of the last render call (rays cast, node visits ...), see DESIGN.md. n <= 16. */
+/* Work counters of the last render call (rays cast, node visits ...), see DESIGN.md: [0..7] events, [8] flop and
+ * [9] transcendental calls by the cost table (ACN_OPT_COUNT_WORK).  [10 + 16 * kernel + phase] (kernel 0 walk, 1 hard
+ * shadow, 2 hard path): shader-clock ticks the kernel's waves spent per phase, filled only by a diagnostic build of
+ * the library (EXTRA_DEFS=-DACN_PHASE_TIMERS), zero otherwise. n <= 64. */
 int acn_last_counters( acn_scene_handle* h, uint64_t* out, int n );
 
 /* MC bounding-sphere estimate of src/objects.c:312-363 for node `node` of an uploaded scene (GPU). */

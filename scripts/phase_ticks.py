@@ -1,0 +1,31 @@
+"""Where the waves of the machine kernels spend their time: python scripts/phase_ticks.py [workload]
+Needs a library built with EXTRA_DEFS=-DACN_PHASE_TIMERS (ACN_LIBDIR points at it)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import actinon_amd as A
+name = sys.argv[1] if len(sys.argv) > 1 else "wine_glass_1080p"
+builder, ov = bench.WORKLOADS[name]
+if builder.startswith("fixture:"):
+    flat = A.Flat.load(os.path.join(bench.ROOT, "tests", "golden", "scenes", builder.split(":")[1] + ".npz"), **ov)
+else:
+    flat = A.Scene.build(builder, **ov).flatten()
+w, h = int(flat.params.image_width), int(flat.params.image_height)
+os.environ.setdefault("ACN_LANES", "1")
+hd = A.Handle(flat)
+import torch
+out = torch.empty((w * h, 3), dtype=torch.float64, device="cuda:0")
+for _ in range(2):
+    hd.render_main_pass_dev(0, w * h, out.data_ptr(), linear=True)
+torch.cuda.synchronize()
+st = hd.last_stages()
+print({k: round(v, 2) for k, v in st.items() if k.endswith("_ms")})
+for kernel, ph in hd.last_phase_ticks().items():
+    tot = sum(ph.values())
+    if not tot:
+        continue
+    print(kernel, "total ticks %.3e" % tot)
+    for p, v in ph.items():
+        if v:
+            print("   %-10s %5.1f %%" % (p, 100.0 * v / tot))
+hd.close()
