@@ -135,6 +135,7 @@ template< class NP >
 struct DevSceneT
 {
     NP nodes;
+    const GNode ACN_CONST* gnodes;   /* the node array in global memory, whatever `nodes` points to (wave-uniform reads: scalar loads) */
     MatP  mats;
     ElemP elems;
     TexP  textures;
@@ -160,7 +161,7 @@ template< class NP2 >
 __device__ __forceinline__ DevSceneT< NP2 > scene_rebind( const DevScene& sc, NP2 nodes )
 {
     DevSceneT< NP2 > r;
-    r.nodes = nodes; r.mats = sc.mats; r.elems = sc.elems; r.textures = sc.textures;
+    r.nodes = nodes; r.gnodes = sc.nodes; r.mats = sc.mats; r.elems = sc.elems; r.textures = sc.textures;
     r.light_root = sc.light_root; r.matter_root = sc.matter_root; r.n_nodes = sc.n_nodes; r.n_elems = sc.n_elems;
     r.prm = sc.prm; r.camera_rotation = sc.camera_rotation; r.unit_f = sc.unit_f; r.flags = sc.flags; r.lds_stack = sc.lds_stack; r.prune_base = sc.prune_base; r.sc_table = sc.sc_table;
     return r;
@@ -251,12 +252,12 @@ __device__ __forceinline__ void phase_flush( unsigned long long* counters, int k
 
 /* the two read-only scene arrays, passed BY VALUE into the non-inlined machines (global address space, so the
  * scene struct is never forced into scratch) */
-template< class NP > struct SceneRefT { NP nodes; ElemP elems; uint32_t* flags; uint32_t n_elems; uint32_t lds_stack; };
+template< class NP > struct SceneRefT { NP nodes; const GNode ACN_CONST* gnodes; ElemP elems; uint32_t* flags; uint32_t n_elems; uint32_t lds_stack; };
 #define ACN_FLAG_TASK_OVERFLOW  1u
 #define ACN_FLAG_CHILD_OVERFLOW 2u
 #define ACN_FLAG_STACK_OVERFLOW 4u   /* CSG / compound / ray stack exhausted: the result would be wrong, the call fails */
 #define ACN_FLAG_CLAMPED        8u   /* a single pixel contribution exceeded the fixed-point clamp (reported, not an error) */
-template< class NP > __device__ __forceinline__ SceneRefT< NP > sref( const DevSceneT< NP >& sc ) { SceneRefT< NP > r; r.nodes = sc.nodes; r.elems = sc.elems; r.flags = sc.flags; r.n_elems = sc.n_elems; r.lds_stack = sc.lds_stack; return r; }
+template< class NP > __device__ __forceinline__ SceneRefT< NP > sref( const DevSceneT< NP >& sc ) { SceneRefT< NP > r; r.nodes = sc.nodes; r.gnodes = sc.gnodes; r.elems = sc.elems; r.flags = sc.flags; r.n_elems = sc.n_elems; r.lds_stack = sc.lds_stack; return r; }
 
 /* ---- vectors.h ---- */
 DEV V3 mk( double x, double y, double z ) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
@@ -730,7 +731,7 @@ template< class NP, class CT > DEV double simple_leaf_hit_( NP g, V3 rp, V3 rd, 
 }
 #define simple_leaf_hit( ... ) simple_leaf_hit_( __VA_ARGS__, cnt )
 
-template< int L, class SR, class CT > DEV double operand_hit( SR sc, int c, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
+template< int L, bool SPLIT = false, class SR, class CT > DEV double operand_hit( SR sc, int c, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
 {
     auto cn = &sc.nodes[ c ];
     cnt->inc( CNT_OBJ_HIT );
@@ -739,7 +740,7 @@ template< int L, class SR, class CT > DEV double operand_hit( SR sc, int c, V3 r
     {
         if( cn->flags & ACN_GFLAG_LEAF_PAIR )
         {
-            double a = pair_hit< L - 1 >( sc, cn, rp, rd, want_nor, nor, cnt );
+            double a = pair_hit< L - 1, SPLIT >( sc, cn, rp, rd, want_nor, nor, cnt );
             if( want_nor && a < F3_INF && cn->surface_roughness > 0 ) *nor = roughness_normal( cn, *nor, ray_pos( rp, rd, a ) );
             return a;
         }
@@ -772,8 +773,8 @@ template< int L, bool SPLIT, class SR, class NP, class CT > DEV double pair_hit(
     int want = ( n->type == ACN_PAIR_INSIDE ) ? -1 : 1;
     int c0 = n->child0, c1 = n->child1;
     V3 n1 = mk( 0, 0, 0 ), n2 = mk( 0, 0, 0 );
-    double a1 = operand_hit< L >( sc, c0, rp, rd, want_nor, &n1, cnt );
-    double a2 = operand_hit< L >( sc, c1, rp, rd, want_nor, &n2, cnt );
+    double a1 = operand_hit< L, SPLIT >( sc, c0, rp, rd, want_nor, &n1, cnt );
+    double a2 = operand_hit< L, SPLIT >( sc, c1, rp, rd, want_nor, &n2, cnt );
     cnt->cost( ACN_F_PAIR_STEP );
     if( a1 < a2 && operand_side< L >( sc, c1, ray_pos( rp, rd, a1 ), cnt ) == want ) { *nor = n1; return a1; }
     if( a2 >= F3_INF ) return F3_INF;
@@ -788,14 +789,14 @@ template< int L, bool SPLIT, class SR, class NP, class CT > DEV double pair_hit(
         int sd;
         if constexpr( SPLIT )
         {
-            if( swapped ) { a = operand_hit< L >( sc, c1, walk_p, rd, want_nor, &n1, cnt ); sd = a < F3_INF ? operand_side< L >( sc, c0, ray_pos( walk_p, rd, a ), cnt ) : 0; }
-            else          { a = operand_hit< L >( sc, c0, walk_p, rd, want_nor, &n1, cnt ); sd = a < F3_INF ? operand_side< L >( sc, c1, ray_pos( walk_p, rd, a ), cnt ) : 0; }
+            if( swapped ) { a = operand_hit< L, SPLIT >( sc, c1, walk_p, rd, want_nor, &n1, cnt ); sd = a < F3_INF ? operand_side< L >( sc, c0, ray_pos( walk_p, rd, a ), cnt ) : 0; }
+            else          { a = operand_hit< L, SPLIT >( sc, c0, walk_p, rd, want_nor, &n1, cnt ); sd = a < F3_INF ? operand_side< L >( sc, c1, ray_pos( walk_p, rd, a ), cnt ) : 0; }
             cnt->cost( ACN_F_PAIR_STEP );
             if( a >= F3_INF ) return F3_INF;
         }
         else
         {
-            a = operand_hit< L >( sc, swapped ? c1 : c0, walk_p, rd, want_nor, &n1, cnt );
+            a = operand_hit< L, SPLIT >( sc, swapped ? c1 : c0, walk_p, rd, want_nor, &n1, cnt );
             cnt->cost( ACN_F_PAIR_STEP );
             if( a >= F3_INF ) return F3_INF;
             sd = operand_side< L >( sc, swapped ? c0 : c1, ray_pos( walk_p, rd, a ), cnt );
@@ -1163,6 +1164,8 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
     }
 }
 
+#include "acn_unimachine.h"
+
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* compounds: compound.c:215-299 */
 
@@ -1485,7 +1488,11 @@ DEV double element_hit( const SC& sc, int e, V3 rp, V3 rd, V3* nor, int* hit_obj
         ACN_LAP( PH_ROOT_LEAF );
         if( type != ACN_DISTANCE && ( surely_outside< ACN_PRUNE_DEPTH >( sc, e, rp, rd ) || prune_run( sc, e, rp, rd, F3_INF ) ) ) { cnt->inc( CNT_OBJ_HIT ); ACN_LAP( PH_PRUNE ); return F3_INF; }
         ACN_LAP( PH_PRUNE );
-        return obj_ray_hit_dev( sref( sc ), e, rp, rd, NOR, nor, cnt );   /* the machine redoes the envelope test */
+#if ACN_UNI_MACHINE
+        return obj_ray_hit_uni< NOR >( sref( sc ), e, rp, rd, nor, cnt );   /* the machine redoes the envelope test */
+#else
+        return obj_ray_hit_dev( sref( sc ), e, rp, rd, NOR, nor, cnt );
+#endif
     }
     cnt->inc( CNT_OBJ_HIT );
     double a;

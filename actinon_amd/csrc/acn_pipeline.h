@@ -539,7 +539,7 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
  * rebuilt inside (scene arrays are then read through the constant address space, see acn_device.h); p_counts is the
  * counter block of the kernel's level. */
 #define ACN_SCENE_PARAMS  DevScene sc_in, const GNode* __restrict__ p_nodes, const GMat* __restrict__ p_mats, const int32_t* __restrict__ p_elems, const acn_texture* __restrict__ p_textures
-#define ACN_SCENE_VIEW    DevScene sc = sc_in; sc.nodes = ( NodeP )p_nodes; sc.mats = ( MatP )p_mats; sc.elems = ( ElemP )p_elems; sc.textures = ( TexP )p_textures; sc.flags = p_counts + QC_FLAGS; sc.lds_stack = ACN_NO_LDS_STACK;
+#define ACN_SCENE_VIEW    DevScene sc = sc_in; sc.nodes = ( NodeP )p_nodes; sc.gnodes = ( NodeP )p_nodes; sc.mats = ( MatP )p_mats; sc.elems = ( ElemP )p_elems; sc.textures = ( TexP )p_textures; sc.flags = p_counts + QC_FLAGS; sc.lds_stack = ACN_NO_LDS_STACK;
 
 /* LDS staging of the node array (kernels whose node reads are per-lane: the CSG machines).  The block copies the
  * GNode array into dynamic shared memory once; per-lane node reads then are ds_read instead of global loads. */

@@ -720,7 +720,7 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     HIP_TRY_H( hipMemcpy( h->d_nodes, nodes.data(), sizeof( GNode ) * scene->n_nodes, hipMemcpyHostToDevice ) );
     HIP_TRY_H( hipMemcpy( h->d_mats, mats.data(), sizeof( GMat ) * scene->n_nodes, hipMemcpyHostToDevice ) );
     HIP_TRY_H( hipMemcpy( h->d_elems, elems2.data(), sizeof( int32_t ) * elems2.size(), hipMemcpyHostToDevice ) );
-    h->dev.nodes = ( NodeP )h->d_nodes;
+    h->dev.nodes = ( NodeP )h->d_nodes; h->dev.gnodes = ( NodeP )h->d_nodes;
     h->dev.mats = ( MatP )h->d_mats;
     h->dev.elems = ( ElemP )h->d_elems;
     h->dev.textures = ( TexP )h->d_textures;
