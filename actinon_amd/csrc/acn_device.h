@@ -241,10 +241,24 @@ __device__ __forceinline__ void phase_flush( unsigned long long* counters, int k
         for( int k = 0; k < ACN_PH_N; k++ ) if( w[ 1 + k ] ) atomicAdd( &counters[ CNT_N + 2 + ACN_PH_N * kernel + k ], w[ 1 + k ] );
     }
 }
+/* diagnostic tallies in the same slots: [ 12 ] lanes that entered a lock-step machine, [ 13 ] machine entries (waves),
+ * [ 14 ] lanes active at leaf evaluations inside it, [ 15 ] leaf evaluations */
+__device__ __forceinline__ void phase_tally( int k, bool x )
+{
+    unsigned long long ex = __ballot( 1 ), m = __ballot( x );
+    if( ( int )( threadIdx.x & 63 ) == __ffsll( ( long long )ex ) - 1 )
+    {
+        unsigned long long* w = acn_phase_lds[ threadIdx.x >> 6 ];
+        w[ 1 + k ] += ( unsigned long long )__popcll( m );
+        w[ 2 + k ] += 1;
+    }
+}
+#define ACN_TALLY( k, x ) phase_tally( k, x )
 #define ACN_LAP( k ) phase_lap( k )
 #define ACN_PHASE_INIT phase_init();
 #define ACN_PHASE_FLUSH( counters, kernel ) phase_flush( counters, kernel );
 #else
+#define ACN_TALLY( k, x )
 #define ACN_LAP( k )
 #define ACN_PHASE_INIT
 #define ACN_PHASE_FLUSH( counters, kernel )

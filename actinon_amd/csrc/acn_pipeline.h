@@ -168,7 +168,7 @@ enum
 };
 
 #ifndef ACN_CLASS0_MIN
-#define ACN_CLASS0_MIN 32
+#define ACN_CLASS0_MIN 128
 #endif
 /* lanes per task of the size classes, and the smallest sample count that goes to each */
 DEV int size_class( uint64_t n )

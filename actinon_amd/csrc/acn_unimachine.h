@@ -194,6 +194,7 @@ DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp, V3 rd, V3* out_nor, CT* 
     bool act = true;
     double ret_a = F3_INF;
     V3 ret_n = mk( 0, 0, 0 );
+    ACN_TALLY( 12, true );
     for( ;; )
     {
         /* ---- EVAL( node, rp, rd ) for the lanes with act ---- */
@@ -211,6 +212,7 @@ DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp, V3 rd, V3* out_nor, CT* 
         }
         else if( type <= ACN_DISTANCE )
         {
+            ACN_TALLY( 14, in );
             if( in )
             {
                 if( type == ACN_PLANE )         ret_a = plane_ray_hit( ld3( n->pos ), ld3( n->rax + 6 ), rp, rd, NOR, &ret_n );
@@ -224,6 +226,7 @@ DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp, V3 rd, V3* out_nor, CT* 
 #if ACN_UNI_PAIR_LEVEL >= 1
         else if( nflags & ( ACN_UNI_PAIR_LEVEL >= 2 ? ( ACN_GFLAG_LEAF_PAIR | ACN_GFLAG_PAIR2 ) : ACN_GFLAG_LEAF_PAIR ) )
         {
+            ACN_TALLY( 14, in );
             if( in )
             {
 #if ACN_UNI_PAIR_LEVEL >= 2

@@ -1188,11 +1188,13 @@ static int make_lane( acn_scene_handle* parent, int lanes, acn_scene_handle** ou
     return ACN_OK;
 }
 
-/* number of lanes for a call of n positions: the handle's ACN_LANES, one lane below 32 tiles per lane */
+/* number of lanes for a call of n positions: the handle's ACN_LANES, fewer while a lane would get less than 32 tiles or
+ * less than ~10^6 path samples' worth of work (a frame without path tracing is over before a second lane has started) */
 static int lanes_for( const acn_scene_handle* h, size_t n )
 {
     int lanes = h->tun.lanes;
-    while( lanes > 1 && n < ( size_t )lanes * 32 * ACN_LANE_TILE ) lanes--;
+    const size_t work = n * ( size_t )( h->dev.prm.path_samples + 1 );
+    while( lanes > 1 && ( n < ( size_t )lanes * 32 * ACN_LANE_TILE || work < ( size_t )lanes << 20 ) ) lanes--;
     return lanes;
 }
 

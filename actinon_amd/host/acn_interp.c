@@ -913,9 +913,10 @@ static acn_v3 V3( double x, double y, double z ) { acn_v3 v = { x, y, z }; retur
  * "#pl<N>'<c>'{ ... }" around them -- what the shipped scripts use (diamond_video.acn:197). */
 static val* string_fa( ev* e, const char* fmt, const val* arg )
 {
-    char out[ 512 ]; size_t n = 0;
-    for( const char* p = fmt; *p && n < sizeof( out ) - 64; )
+    char out[ 1024 ]; size_t n = 0;
+    for( const char* p = fmt; *p; )
     {
+        if( n >= sizeof( out ) - 320 ) FAIL( e, "string_fa: result longer than %d characters.", ( int )sizeof( out ) - 320 );
         if( *p != '#' ) { out[ n++ ] = *p++; continue; }
         int pad = 0; char padc = ' ';
         const char* q = p + 1;
@@ -929,13 +930,14 @@ static val* string_fa( ev* e, const char* fmt, const val* arg )
             if( *q != '#' ) FAIL( e, "string_fa: unsupported format '%s'.", fmt );
             q++;
         }
-        char item[ 64 ];
+        char item[ 256 ];
         if( !strncmp( q, "<s3_t*>", 7 ) ) { if( !is_num( arg ) ) FAIL( e, "string_fa: number expected." ); snprintf( item, sizeof( item ), "%lld", ( long long )( arg->type == V_FLOAT ? ( int64_t )arg->u.f : arg->type == V_INT ? arg->u.i : arg->u.b ) ); q += 7; }
         else if( !strncmp( q, "<f3_t*>", 7 ) ) { if( !is_num( arg ) ) FAIL( e, "string_fa: number expected." ); fmt_f3( item, sizeof( item ), to_f3( arg ) ); q += 7; }
-        else if( !strncmp( q, "<sc_t>", 6 ) ) { if( arg->type != V_STR ) FAIL( e, "string_fa: string expected." ); snprintf( item, sizeof( item ), "%s", arg->u.s ); q += 6; }
+        else if( !strncmp( q, "<sc_t>", 6 ) ) { if( arg->type != V_STR ) FAIL( e, "string_fa: string expected." ); if( strlen( arg->u.s ) >= sizeof( item ) ) FAIL( e, "string_fa: string argument longer than %d characters.", ( int )sizeof( item ) - 1 ); snprintf( item, sizeof( item ), "%s", arg->u.s ); q += 6; }
         else FAIL( e, "string_fa: unsupported format '%s'.", fmt );
         if( braced ) { if( *q != '}' ) FAIL( e, "string_fa: unsupported format '%s'.", fmt ); q++; }
-        for( int l = ( int )strlen( item ); l < pad && n < sizeof( out ) - 64; l++ ) out[ n++ ] = padc;
+        if( pad > 255 ) FAIL( e, "string_fa: padding wider than 255." );
+        for( int l = ( int )strlen( item ); l < pad; l++ ) out[ n++ ] = padc;
         n += ( size_t )snprintf( out + n, sizeof( out ) - n, "%s", item );
         p = q;
     }

@@ -299,6 +299,11 @@ class Handle:
     PHASES = ["other", "light", "root_leaf", "prune", "m_leaf", "m_pair", "m_frame", "m_side", "shade", "compound", "fetch",
               "tail"]
 
+    def last_counters_raw(self, n):
+        buf = (C.c_uint64 * n)()
+        check(hip.acn_last_counters(self.h, buf, n), "acn_last_counters")
+        return [int(v) for v in buf]
+
     def last_phase_ticks(self):
         """{kernel: {phase: shader-clock ticks}} of a library built with -DACN_PHASE_TIMERS (all zero otherwise)"""
         buf = (C.c_uint64 * 58)()

@@ -21,11 +21,16 @@ torch.cuda.synchronize()
 st = hd.last_stages()
 print({k: round(v, 2) for k, v in st.items() if k.endswith("_ms")})
 for kernel, ph in hd.last_phase_ticks().items():
-    tot = sum(ph.values())
+    tot = sum(ph.values())  # the tally slots are outside the named phases
     if not tot:
         continue
     print(kernel, "total ticks %.3e" % tot)
     for p, v in ph.items():
         if v:
             print("   %-10s %5.1f %%" % (p, 100.0 * v / tot))
+buf = hd.last_counters_raw(58)
+for k, kernel in enumerate(["walk", "hard_shadow", "hard_path"]):
+    t = [buf[10 + 16 * k + i] for i in (12, 13, 14, 15)]
+    if t[1]:
+        print("%s: %.1f of 64 lanes enter a lock-step machine (%d entries); %.1f lanes per leaf / in-line pair evaluation (%d)" % (kernel, t[0] / t[1], t[1], t[2] / max(t[3], 1), t[3]))
 hd.close()

@@ -51,11 +51,14 @@ def test_detmath_bit_identical_cpu_gpu(detmath_cpu):
     assert np.array_equal(A.detmath_eval("sqrt", np.abs(sub)).view(np.uint64), np.sqrt(np.abs(sub)).view(np.uint64))
 
 
+@pytest.mark.parametrize("count_work", [False, True], ids=["production_kernels", "instrumented_kernels"])
 @pytest.mark.parametrize("name", list(S.SMALL))
-def test_image_parity_with_oracle(oracle, name):
+def test_image_parity_with_oracle(oracle, name, count_work):
+    """Both builds of the pipeline kernels -- the ones every render uses and the ones ACN_OPT_COUNT_WORK selects --
+    against the oracle, pixel by pixel."""
     sc, flat = S.build(name)
     pos = S.positions(flat)
-    h = A.Handle(flat, count_work=True)
+    h = A.Handle(flat, count_work=count_work)
     for linear in (True, False):
         gpu = h.render_positions(pos, linear=linear)
         cpu = oracle.render_positions(flat, pos, linear=linear)

@@ -96,6 +96,15 @@ def test_errors_carry_file_and_line(tmp_path):
     assert "Cannot evaluate 'object' AND 'int'" in str(e.value)
     with pytest.raises(A.AcnError):
         A.Scene.from_script(tmp_path / "missing.acn", SKIP)
+    # string_fa never truncates silently: what does not fit its buffers is an error
+    p.write_text('def t = "' + "x" * 300 + '";\ndef u = string_fa( "#<sc_t>", t );\n')
+    with pytest.raises(A.AcnError) as e:
+        A.Scene.from_script(p, SKIP)
+    assert "bad.acn:2" in str(e.value) and "longer than" in str(e.value)
+    p.write_text('def u = string_fa( "' + "y" * 900 + '#<s3_t*>", 7 );\n')
+    with pytest.raises(A.AcnError) as e:
+        A.Scene.from_script(p, SKIP)
+    assert "longer than" in str(e.value)
 
 
 def test_create_image_hook_and_readonly_fs(tmp_path):
