@@ -142,6 +142,7 @@ struct acn_scene_handle
     bool stage_timing = false;                 /* ACN_OPT_STAGE_TIMING of the current call */
     int max_csg_depth = 0;
     Tunables tun;
+    unsigned cus = 256;                        /* compute units of the device */
     unsigned grid = 1024, shade_grid = 1024;   /* workgroups of the persistent kernels / of k_shade */
     int n_levels = 1;                          /* path levels of the scene's trace_depth */
     /* workspace of the wavefront pipeline */
@@ -456,7 +457,12 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     {
         int cus = 0;
         if( hipDeviceGetAttribute( &cus, hipDeviceAttributeMultiprocessorCount, device ) != hipSuccess || cus <= 0 ) cus = 256;
-        h->grid = h->tun.grid ? h->tun.grid : ( unsigned )cus * 4u;               /* 4 workgroups of 256 lanes per CU: occupancy 4 */
+        /* persistent grids.  A call that runs alone on its stream: 4 workgroups of 256 lanes per CU, what fits of the
+         * 128-VGPR kernels.  The concurrent lanes of a call (create_lane): 2 per CU each -- what is resident of k_walk
+         * (256 VGPRs); four lanes keep the chip full and leave room for each other's kernels (1080p: 83.4 ms against
+         * 85.2 with 4 per CU; a lone lane with 2 per CU: 106 ms against 88) */
+        h->cus = ( unsigned )cus;
+        h->grid = h->tun.grid ? h->tun.grid : ( unsigned )cus * 4u;
         h->shade_grid = h->tun.shade_grid ? h->tun.shade_grid : ( unsigned )cus * 4u;
         /* path levels: level L shades hits at depth trace_depth - 10 L and spawns the next one while that is > 10 (scene.c:584) */
         uint64_t td = scene->params.trace_depth;
@@ -1170,7 +1176,9 @@ static int make_lane( acn_scene_handle* parent, int lanes, acn_scene_handle** ou
     l->max_csg_depth = parent->max_csg_depth;
     l->lds_bytes = parent->lds_bytes; l->lds_stack_bytes = parent->lds_stack_bytes;
     l->prune = parent->prune; l->leaf_lights = parent->leaf_lights;
-    l->tun = parent->tun; l->grid = parent->grid; l->shade_grid = parent->shade_grid; l->n_levels = parent->n_levels;
+    l->tun = parent->tun; l->cus = parent->cus; l->n_levels = parent->n_levels;
+    l->grid = parent->tun.grid ? parent->tun.grid : parent->cus * 2u;
+    l->shade_grid = parent->tun.shade_grid ? parent->tun.shade_grid : parent->cus * 2u;
 #define HIP_TRY_L( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) { acn_scene_free( l ); return fail( ACN_ERR_DEVICE, hipGetErrorString( e_ ) ); } } while( 0 )
     HIP_TRY_L( hipStreamCreateWithFlags( &l->stream, hipStreamNonBlocking ) );
     HIP_TRY_L( hipEventCreate( &l->ev0 ) );

@@ -49,7 +49,7 @@ WORKLOADS = {
 }
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-GRID_WORKGROUPS = 1024   # persistent kernels: 4 workgroups of 256 lanes per compute unit (acn_scene_upload)
+GRID_WORKGROUPS = 512    # persistent kernels of a lane: 2 workgroups of 256 lanes per compute unit (create_lane in actinon_hip.hip)
 FP64_PEAK_TFLOPS = 78.6  # fp64 vector (non-MFMA) peak = half the guide's 157.3 TFLOP/s fp32 vector peak; counts an FMA as 2
 
 
