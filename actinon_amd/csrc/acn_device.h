@@ -148,6 +148,7 @@ struct DevSceneT
     uint32_t* flags;     /* device word for ACN_FLAG_* error bits */
     uint32_t lds_stack;  /* byte offset of the CSG stack area in dynamic LDS, ACN_NO_LDS_STACK if the kernel has none */
     uint32_t prune_base; /* elems[ prune_base + node ]: offset of the node's prune program in elems[], or -1 */
+    uint32_t class0_min; /* shading tasks with more samples than this run on 64 lanes (ACN_CLASS0_MIN, acn_pipeline.h: size_class) */
     const SCEntry* sc_table;   /* pre-order tables of the simple compounds */
     static constexpr bool prune = false;
 };
@@ -163,7 +164,7 @@ __device__ __forceinline__ DevSceneT< NP2 > scene_rebind( const DevScene& sc, NP
     DevSceneT< NP2 > r;
     r.nodes = nodes; r.gnodes = sc.nodes; r.mats = sc.mats; r.elems = sc.elems; r.textures = sc.textures;
     r.light_root = sc.light_root; r.matter_root = sc.matter_root; r.n_nodes = sc.n_nodes; r.n_elems = sc.n_elems;
-    r.prm = sc.prm; r.camera_rotation = sc.camera_rotation; r.unit_f = sc.unit_f; r.flags = sc.flags; r.lds_stack = sc.lds_stack; r.prune_base = sc.prune_base; r.sc_table = sc.sc_table;
+    r.prm = sc.prm; r.camera_rotation = sc.camera_rotation; r.unit_f = sc.unit_f; r.flags = sc.flags; r.lds_stack = sc.lds_stack; r.prune_base = sc.prune_base; r.class0_min = sc.class0_min; r.sc_table = sc.sc_table;
     return r;
 }
 
@@ -208,7 +209,7 @@ template<> struct Cnt< false >
  * accumulators in LDS; ACN_LAP( k ) books the shader-clock time since the wave's previous mark on phase k, whichever
  * lanes are active.  phase_flush adds the wave's sums to counters[ CNT_N + 2 + 16 * kernel + k ] at kernel end. */
 #define ACN_PH_N 16
-#define ACN_PH_KERNELS 3
+#define ACN_PH_KERNELS 4
 #define ACN_CNT_SLOTS ( CNT_N + 2 + ACN_PH_N * ACN_PH_KERNELS )
 enum { PH_OTHER = 0, PH_LIGHT, PH_ROOT_LEAF, PH_PRUNE, PH_M_LEAF, PH_M_PAIR, PH_M_FRAME, PH_M_SIDE, PH_SHADE, PH_COMPOUND, PH_FETCH, PH_TAIL };
 #ifdef ACN_PHASE_TIMERS

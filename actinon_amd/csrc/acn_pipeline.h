@@ -171,16 +171,14 @@ enum
  * Narrow groups lose less in the last, partly filled round of a sample loop (200 samples on 64 lanes: 4 rounds, 78 %
  * of the lanes busy; on 16 lanes: 13 rounds, 96 %), and the tasks that share a wave are neighbours with similar counts.
  * Measured on the 1080p frame: every task above 8 samples on 16 lanes 79.8 ms, the 64-lane class from 129 samples 84.0,
- * from 33 samples 85.2 -- so the 64-lane class is kept only for counts no scene reaches with the reference's limits. */
-#ifndef ACN_CLASS0_MIN
-#define ACN_CLASS0_MIN 1000000
-#endif
+ * from 33 samples 85.2 -- so the 64-lane class is kept only for counts no shipped scene reaches; the environment
+ * variable ACN_CLASS0_MIN lowers the limit (tests run both arrangements). */
 #ifndef ACN_CLASS1_MIN
 #define ACN_CLASS1_MIN 8
 #endif
-DEV int size_class( uint64_t n )
+DEV int size_class( uint64_t n, uint32_t class0_min )   /* class0_min: DevScene.class0_min (ACN_CLASS0_MIN, default 1 000 000) */
 {
-    return n > ACN_CLASS0_MIN ? 0 : n > ACN_CLASS1_MIN ? 1 : n > 2 ? 2 : 3;
+    return n > class0_min ? 0 : n > ACN_CLASS1_MIN ? 1 : n > 2 ? 2 : 3;
 }
 
 /* ------------------------------------------------------------------------------------------------------------------ */
@@ -477,7 +475,7 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
         uint32_t slot = chunk_alloc( tcs, &tq.counts[ QC_TASKS ], emit );
         bool ok = emit && slot < tq.task_cap;
         if( emit && !ok ) atomicOr( &tq.counts[ QC_FLAGS ], ACN_FLAG_TASK_OVERFLOW );
-        int cls = ok ? size_class( n_direct > n_path ? n_direct : n_path ) : -1;
+        int cls = ok ? size_class( n_direct > n_path ? n_direct : n_path, sc.class0_min ) : -1;
         if( ok )
         {
             DTask& t = tq.tasks[ slot ];
@@ -795,6 +793,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
     const auto scp = scene_view< PRUNE >( sc, sc.nodes );   /* the scene as the two root-traversal fast paths see it */
     const ChunkP cs = ACN_CHUNKS_OF_WAVE;                   /* [0] hard shadow, [1] hard path, [2] children */
     chunks_init( cs );
+    ACN_PHASE_INIT
     constexpr int G = 64 / LPT;
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPT;
@@ -863,6 +862,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
             uint64_t rvj = lcg_jump_lane( rv0, sub );
             for( uint64_t j = j_lo + sub; j < j_hi; j += LPT )
             {
+                ACN_TALLY( 0, true );   /* diagnostic build: lanes in a round of the direct-light loop */
                 uint64_t r = rvj;
                 rvj = lcg_stride< LPT >( rvj );
                 cnt.inc( CNT_CAP_SAMPLE );
@@ -928,6 +928,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
             uint64_t rvj = lcg_jump_lane( rv0, sub );
             for( uint64_t j = j_lo + sub; j < j_hi; j += LPT )
             {
+                ACN_TALLY( 2, true );   /* ... of the path loop */
                 uint64_t r = rvj;
                 rvj = lcg_stride< LPT >( rvj );
                 cnt.inc( CNT_CAP_SAMPLE );
@@ -994,6 +995,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
     wave_stat_add( p_counts + QS_HARD_SHADOW, n_hs );
     wave_stat_add( p_counts + QS_HARD_PATH, n_hp );
     wave_stat_add( p_counts + QS_CHILDREN, n_ch );
+    ACN_PHASE_FLUSH( counters, 3 )
     wave_add_counters( counters, cnt );
 }
 

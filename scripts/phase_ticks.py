@@ -28,9 +28,12 @@ for kernel, ph in hd.last_phase_ticks().items():
     for p, v in ph.items():
         if v:
             print("   %-10s %5.1f %%" % (p, 100.0 * v / tot))
-buf = hd.last_counters_raw(58)
+buf = hd.last_counters_raw(64)
 for k, kernel in enumerate(["walk", "hard_shadow", "hard_path"]):
     t = [buf[10 + 16 * k + i] for i in (12, 13, 14, 15)]
     if t[1]:
         print("%s: %.1f of 64 lanes enter a lock-step machine (%d entries); %.1f lanes per leaf / in-line pair evaluation (%d)" % (kernel, t[0] / t[1], t[1], t[2] / max(t[3], 1), t[3]))
+t = [buf[10 + 16 * 3 + i] for i in range(4)]
+if t[1]:
+    print("k_shade: %.1f of 64 lanes per round of the direct-light loops (%d rounds), %.1f per round of the path loops (%d)" % (t[0] / t[1], t[1], t[2] / max(t[3], 1), t[3]))
 hd.close()
