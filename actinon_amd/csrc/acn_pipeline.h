@@ -169,14 +169,13 @@ enum
 
 /* Size classes of the shading tasks: 64 / 16 / 4 / 1 lanes per task, by the larger of the task's two sample counts.
  * Narrow groups lose less in the last, partly filled round of a sample loop (200 samples on 64 lanes: 4 rounds, 78 %
- * of the lanes busy; on 16 lanes: 13 rounds, 96 %), and the tasks that share a wave are neighbours with similar counts.
- * Measured on the 1080p frame: every task above 8 samples on 16 lanes 79.8 ms, the 64-lane class from 129 samples 84.0,
- * from 33 samples 85.2 -- so the 64-lane class is kept only for counts no shipped scene reaches; the environment
- * variable ACN_CLASS0_MIN lowers the limit (tests run both arrangements). */
+ * of the lanes busy; on 16 lanes: 13 rounds, 96 %), and the tasks that share a wave are neighbours with similar counts;
+ * a whole wavefront per task keeps the rays of a round on one origin.  Where the 64-lane class begins is chosen per
+ * scene at upload (DevScene.class0_min, see there; ACN_CLASS0_MIN overrides). */
 #ifndef ACN_CLASS1_MIN
 #define ACN_CLASS1_MIN 8
 #endif
-DEV int size_class( uint64_t n, uint32_t class0_min )   /* class0_min: DevScene.class0_min (ACN_CLASS0_MIN, default 1 000 000) */
+DEV int size_class( uint64_t n, uint32_t class0_min )
 {
     return n > class0_min ? 0 : n > ACN_CLASS1_MIN ? 1 : n > 2 ? 2 : 3;
 }

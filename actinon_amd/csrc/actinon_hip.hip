@@ -80,7 +80,7 @@ struct Tunables
     uint32_t fetch_walk = 64;          /* ACN_FETCH_WALK: fresh rays a k_walk wave reserves per cursor atomic */
     uint32_t walk_passes = 12;         /* ACN_WALK_PASSES: launches of k_walk per path level (the last one finishes whatever is left) */
     uint32_t private_limit = 32768;    /* ACN_PRIVATE_LIMIT: a generation of at most this many rays is finished on private stacks */
-    uint32_t class0_min = 1000000;     /* ACN_CLASS0_MIN: shading tasks with more samples than this take the 64-lane kernel, the others 16 / 4 / 1 lanes */
+    uint32_t class0_min = 0;           /* ACN_CLASS0_MIN: shading tasks with more samples than this take the 64-lane kernel, the others 16 / 4 / 1 lanes; 0: chosen per scene (acn_scene_upload) */
     uint32_t fetch_shade = 16;         /* ACN_FETCH_SHADE: steps ( of 64 / lanes-per-task tasks ) a k_shade wave reserves per cursor atomic */
     uint32_t fetch_hard = 256;         /* ACN_FETCH_HARD: records a wave of the hard-ray kernels / k_shade_hits reserves per atomic */
     uint32_t stack_use = 0;            /* ACN_TEST_STACK_USE: slots of a private stack every walk pass but the last uses (tests of the overflow path) */
@@ -719,7 +719,12 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     HIP_TRY_H( hipMalloc( &h->d_sc_table, sizeof( SCEntry ) * ( sc_table.size() ? sc_table.size() : 1 ) ) );
     if( sc_table.size() ) HIP_TRY_H( hipMemcpy( h->d_sc_table, sc_table.data(), sizeof( SCEntry ) * sc_table.size(), hipMemcpyHostToDevice ) );
     h->dev.sc_table = h->d_sc_table;
-    h->dev.class0_min = h->tun.class0_min;
+    /* Width of a shading task (size_class in acn_pipeline.h).  Narrow groups waste less of a sample loop's last round;
+     * a whole wavefront per point keeps the rays of a round on one origin, which pays when a sample's traversal is long
+     * and divergent (nested compounds, CSG objects with prune programs: the scenes of the "extras" kernel variants).
+     * Measured, 4 lanes: wine_glass 1080p (200 / 64 samples) 79.8 ms narrow, 85.2 wide from 33 samples; many_spheres
+     * 1080p p256 every 16th pixel 3.94 s narrow, 2.90 s wide; diamond 1080p p512 4.58 s narrow, 4.05 s wide. */
+    h->dev.class0_min = h->tun.class0_min ? h->tun.class0_min : ( h->prune ? 32u : 255u );
     HIP_TRY_H( hipMalloc( &h->d_textures, sizeof( acn_texture ) * ( scene->n_textures ? scene->n_textures : 1 ) ) );
     if( scene->n_textures ) HIP_TRY_H( hipMemcpy( h->d_textures, scene->textures, sizeof( acn_texture ) * scene->n_textures, hipMemcpyHostToDevice ) );
     HIP_TRY_H( hipMalloc( &h->d_counters, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );

@@ -63,10 +63,10 @@ def need_gpu():
 @pytest.mark.parametrize("wide", [False, True], ids=["tasks_on_16_lanes", "tasks_on_64_lanes"])
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_config_at_stated_size_matches_oracle_on_strided_pixels(oracle, name, wide, monkeypatch):
-    """wide: shading tasks above 32 samples take k_shade<64> (ACN_CLASS0_MIN=32) -- the arrangement of round 1, kept for
-    sample counts beyond the default limit; 8- and 16-round sample loops at these configs' 256 - 1024 path samples."""
-    if wide:
-        monkeypatch.setenv("ACN_CLASS0_MIN", "32")
+    """Both widths of a shading task (size_class in acn_pipeline.h): a whole wavefront per point above 32 samples -- 8- and
+    16-round sample loops of k_shade<64> at these configs' 256 - 1024 path samples, the library's choice for these scenes --
+    and 16 lanes per point whatever the count."""
+    monkeypatch.setenv("ACN_CLASS0_MIN", "32" if wide else "1000000")
     builder, ov, count = CONFIGS[name]
     flat = load(builder, ov)
     assert int(flat.params.path_samples) == ov["path_samples"] and int(flat.params.image_width) == ov["image_width"]
