@@ -26,7 +26,8 @@ struct LevelQ
 {
     DTask* tasks; uint32_t* idx[ ACN_NCLASS ]; uint32_t task_cap;
     HitRec* children; uint32_t child_cap;
-    HardShadow* hard_shadow; HardPath* hard_path; uint32_t hard_cap;
+    HardShadow* hard_shadow; uint32_t hs_cap;               /* twice the other queues: it also takes the probes of the walk (probe_push) */
+    HardPath* hard_path; uint32_t hard_cap;
     RayTask* rays[ 2 ]; uint32_t ray_cap;                   /* generation g of the walk waits in rays[ g & 1 ] */
     RayTask* stacks; uint32_t stack_cap;                    /* private ray stacks of the k_walk waves: grid * 4 of them */
     uint32_t stack_use;                                     /* slots of a stack every pass but the last uses (< stack_cap: tests) */
@@ -61,7 +62,7 @@ void acn_launch_hard_path( KernelFlags f, const LevelQ& q, size_t lds_bytes, hip
                            unsigned long long* accum, unsigned long long* counters );
 
 #define ACN_SCENE_ARGS_OF( s ) ( s ).dev, ( s ).nodes, ( s ).mats, ( s ).elems, ( s ).textures
-#define ACN_TASKQ_ARGS_OF( q ) ( q ).tasks, ( q ).idx[ 0 ], ( q ).idx[ 1 ], ( q ).idx[ 2 ], ( q ).idx[ 3 ], ( q ).counts, ( q ).task_cap
+#define ACN_TASKQ_ARGS_OF( q ) ( q ).tasks, ( q ).idx[ 0 ], ( q ).idx[ 1 ], ( q ).idx[ 2 ], ( q ).idx[ 3 ], ( q ).counts, ( q ).task_cap, ( q ).hard_shadow, ( q ).hs_cap, ( q ).emit_terms
 
 /* k_walk< C, L, R > */
 #define ACN_LW_( C, L, R ) \
@@ -80,6 +81,6 @@ void NAME( KernelFlags f, const LevelQ& q, hipStream_t stream, const SceneArgs& 
     else               { if( f.leaf_lights ) ACN_LS_( LPT, CLS, false, true, false ); else ACN_LS_( LPT, CLS, false, false, false ); } \
 }
 #define ACN_LS_( LPT, CLS, C, L, P ) hipLaunchKernelGGL( ( k_shade< LPT, C, L, P > ), dim3( q.shade_grid ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS_OF( s ), \
-    ( const DTask* )q.tasks, ( const uint32_t* )q.idx[ CLS ], CLS, q.task_cap, q.fetch_shade * ( 64u / LPT ), q.children, q.child_cap, q.hard_shadow, q.hard_path, q.hard_cap, q.counts, q.shard_rank, q.shard_world, accum, counters )
+    ( const DTask* )q.tasks, ( const uint32_t* )q.idx[ CLS ], CLS, q.task_cap, q.fetch_shade * ( 64u / LPT ), q.children, q.child_cap, q.hard_shadow, q.hard_path, q.hs_cap, q.hard_cap, q.counts, q.shard_rank, q.shard_world, accum, counters )
 
 #endif

@@ -138,7 +138,7 @@ struct HardShadow
     V3 pos, d;
     double limit;        /* distance of the light hit */
     V3 contrib;          /* what the sample adds to the pixel if it is not occluded */
-    uint32_t pixel, pad; /* pixel == ACN_INVALID: dead slot */
+    uint32_t pixel, pad; /* pixel == ACN_INVALID: dead slot.  pad bit 0: a probe of a specular ray (see probe_push): the light root counts too */
 };
 
 /* a path ray of k_shade that did: k_hard_path finishes the transition hit */
@@ -308,6 +308,9 @@ struct TaskQ
     uint32_t* idx[ ACN_NCLASS ];
     uint32_t* counts;               /* counter block of the level */
     uint32_t  task_cap;
+    HardShadow* probes;             /* the level's hard-shadow queue: where probe_push appends */
+    uint32_t  probe_cap;
+    uint32_t  emit_terms;           /* 0: pixel terms under no sharded sample loop are dropped (ACN_SHARD_SAMPLES, level 0, rank > 0) */
 };
 
 /* a ray queue in global memory (k_shade_hits -> k_walk; generation g -> generation g + 1 of k_walk) */
@@ -369,6 +372,39 @@ struct WalkSink
         if( new_top > cap ) out.push( want && !fits, p, d, T, intensity, depth, pixel );   /* wave-uniform branch */
     }
 };
+
+/* Rays that only need a yes / no.  scene_s_lum returns zero at once when depth == 0 or intensity < trace_min_intensity
+ * (scene.c:430), so for a child ray that is born that way -- the Fresnel reflection off a polished floor seen through one
+ * diffuse bounce, say: 4 % of an intensity of 0.4 is below the 0.03 of the shipped scripts -- the reference's
+ *     if( scene_s_trans_hit( ... ) < f3_inf ) lum_l = scene_s_lum( ... ) [ = 0 ];  else lum_l = background * intensity;
+ * (scene.c:484-491, 507-514, 644-651) asks only WHETHER the ray hits anything.  Such rays do not join the ray queue of
+ * k_walk (closest hit, normal, media transition, the CSG machine with normals); they become records of the level's
+ * hard-shadow queue: an any-hit test over both roots with the cheap elements first, early exit, no normals -- and the
+ * background term added if nothing is hit (k_hard_shadow).  Same value, same fixed-point sum.
+ * limit: hits at or beyond it do not count; F3_BIG = the largest finite double stands for "any finite hit". */
+#define F3_BIG 1.7976931348623157e308
+DEV void probe_push( const TaskQ& tq, ChunkP pcs, bool want, V3 p, V3 d, double limit, V3 contrib, uint32_t pixel, uint32_t flags )
+{
+    uint32_t slot = chunk_alloc( pcs, &tq.counts[ QC_HARD_SHADOW ], want );
+    if( want )
+    {
+        if( slot < tq.probe_cap )
+        {
+            HardShadow& h = tq.probes[ slot ];
+            h.pos = p; h.d = d; h.limit = limit; h.contrib = contrib; h.pixel = pixel; h.pad = flags;
+        }
+        else atomicOr( &tq.counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+    }
+}
+/* a specular child of shade_hit: onto the ray queue if scene_s_lum would look at its hit, else a probe */
+template< class RAYS, class CT >
+DEV void spawn_child( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs, bool f, V3 p, V3 d, V3 T, double intensity, int depth, uint32_t pixel, CT* cnt )
+{
+    const bool dead = f && ( depth == 0 || intensity < sc.prm.trace_min_intensity );
+    rays.push( f && !dead, p, d, T, intensity, depth, pixel );
+    if( dead ) cnt->add( CNT_TRANS_RAY, 2u );   /* the two compound_s_ray_trans_hit calls of scene_s_trans_hit this ray stands for */
+    probe_push( tq, tcs + 6, dead && tq.emit_terms, p, d, F3_BIG, v_mld( T, v_mlf( ld3( sc.prm.background_color ), intensity ) ), pixel, 1u );
+}
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* scene_s_lum for one hit, everything except the two sample loops (scene.c:420-537, 623-664).  Specular children
@@ -437,7 +473,7 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
         V3 out_d = rd;
         double reflectance = 0;
         if( f ) { cnt->cost( ACN_F_FRESNEL_REFL ); reflectance = fresnel_reflection( rd, trans.exit_nor, trix, &out_d ) * fresnel_reflectivity; }
-        rays.push( f, pos, out_d, T, reflectance * intensity, depth - 1, pixel );
+        spawn_child( sc, rays, tq, tcs, f, pos, out_d, T, reflectance * intensity, depth - 1, pixel, cnt );
         if( f ) intensity *= ( 1.0 - reflectance );
     }
 
@@ -446,7 +482,7 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
         bool f = go && chromatic_reflectivity > 0 && intensity >= min_intensity;
         V3 out_d = rd;
         if( f ) { cnt->cost( ACN_F_REFLECTION ); out_d = v_reflection( rd, trans.exit_nor ); }
-        rays.push( f, pos, out_d, v_mld( T, enter_color ), chromatic_reflectivity * intensity, depth - 1, pixel );
+        spawn_child( sc, rays, tq, tcs, f, pos, out_d, v_mld( T, enter_color ), chromatic_reflectivity * intensity, depth - 1, pixel, cnt );
         if( f ) intensity *= ( 1.0 - chromatic_reflectivity );
     }
 
@@ -508,13 +544,17 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
         bool f = go && transparent && intensity >= min_intensity;
         V3 out_d = rd;
         if( f ) { cnt->cost( ACN_F_FRESNEL_REFR ); out_d = fresnel_refraction( rd, trans.exit_nor, trix ); }
-        rays.push( f, ray_pos( rp, rd, offs + 2.0 * F3_EPS ), out_d, T, intensity, depth - 1, pixel );
+        spawn_child( sc, rays, tq, tcs, f, ray_pos( rp, rd, offs + 2.0 * F3_EPS ), out_d, T, intensity, depth - 1, pixel, cnt );
     }
 }
 
-/* the index lists' reservations of a wave end with the kernel */
+/* the index lists' reservations of a wave end with the kernel, and that of its probes */
 DEV void task_chunks_close( const TaskQ& tq, ChunkP tcs )
 {
+    {
+        HardShadow* pr = tq.probes;
+        chunk_close( tcs + 6, tq.probe_cap, [ pr ]( uint32_t j ) { pr[ j ].pixel = ACN_INVALID; } );
+    }
     for( int k = 0; k < ACN_NCLASS; k++ )
     {
         uint32_t* list = tq.idx[ k ];
@@ -556,11 +596,12 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
     }
 
 #define ACN_TASKQ_PARAMS DTask* __restrict__ p_tasks, uint32_t* __restrict__ p_idx0, uint32_t* __restrict__ p_idx1, \
-    uint32_t* __restrict__ p_idx2, uint32_t* __restrict__ p_idx3, uint32_t* __restrict__ p_counts, uint32_t task_cap
+    uint32_t* __restrict__ p_idx2, uint32_t* __restrict__ p_idx3, uint32_t* __restrict__ p_counts, uint32_t task_cap, \
+    HardShadow* __restrict__ p_probes, uint32_t probe_cap, uint32_t probe_emit
 #define ACN_TASKQ_VIEW \
     TaskQ tq; \
     tq.tasks = p_tasks; tq.idx[ 0 ] = p_idx0; tq.idx[ 1 ] = p_idx1; tq.idx[ 2 ] = p_idx2; tq.idx[ 3 ] = p_idx3; \
-    tq.counts = p_counts; tq.task_cap = task_cap;
+    tq.counts = p_counts; tq.task_cap = task_cap; tq.probes = p_probes; tq.probe_cap = probe_cap; tq.emit_terms = probe_emit;
 
 #ifndef ACN_TRACE_WAVES
 #define ACN_TRACE_WAVES ACN_WALK_WAVES
@@ -784,7 +825,7 @@ template< int LPT, bool COUNT, bool LEAF_LIGHTS, bool PRUNE >
 __global__ __launch_bounds__( 256, ACN_SHADE_WAVES )
 void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t* __restrict__ idx, int cls, uint32_t task_cap, uint32_t fetch_batch,
               HitRec* __restrict__ p_children, uint32_t child_cap, HardShadow* __restrict__ p_hard_shadow,
-              HardPath* __restrict__ p_hard_path, uint32_t hard_cap, uint32_t* __restrict__ p_counts, uint32_t shard_rank, uint32_t shard_world,
+              HardPath* __restrict__ p_hard_path, uint32_t hs_cap, uint32_t hard_cap, uint32_t* __restrict__ p_counts, uint32_t shard_rank, uint32_t shard_world,
               unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_CHUNK_STATES
@@ -800,6 +841,8 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
     Cnt< COUNT > cnt;
     cnt.clear();
     const V3 bg = ld3( sc.prm.background_color );
+    /* "a < max_path_length" as the any-hit limit "a <= path_limit": the largest double below it */
+    const double path_limit = sc.prm.max_path_length < F3_INF ? acn_bits_f64( acn_f64_bits( sc.prm.max_path_length ) - 1ull ) : F3_BIG;
     uint32_t n_tasks = p_counts[ QC_CLASS0 + cls ];
     n_tasks = n_tasks < task_cap ? n_tasks : task_cap;
     n_tasks = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n_tasks );
@@ -885,7 +928,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 uint32_t hs = chunk_alloc( cs + 0, &p_counts[ QC_HARD_SHADOW ], occ == 2 );
                 if( occ == 2 )
                 {
-                    if( hs < hard_cap )
+                    if( hs < hs_cap )
                     {
                         HardShadow& h = p_hard_shadow[ hs ];
                         double f = c * ( 2.0 * cyl_hgt / direct_samples );
@@ -947,6 +990,29 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 }
                 bool hit = live && !hard && a < sc.prm.max_path_length;
                 if( live && !hard && !hit ) bsum += weight * diffuse_intensity;
+                /* scene_s_lum of a hit with depth - 10 == 0 or too little intensity is zero (scene.c:430): such a hit is not
+                 * queued, and such a ray that needs the machine only needs a yes / no (see probe_push) */
+                const bool dark = t.depth - 10 == 0 || weight * diffuse_intensity < sc.prm.trace_min_intensity;
+                if( dark ) hit = false;
+                const bool probe = hard && dark;
+                if( probe ) hard = false;
+                uint32_t ps = chunk_alloc( cs + 0, &p_counts[ QC_HARD_SHADOW ], probe );
+                if( probe )
+                {
+                    cnt.inc( CNT_TRANS_RAY );   /* the compound_s_ray_trans_hit this probe stands for */
+                    if( ps < hs_cap )
+                    {
+                        HardShadow& h = p_hard_shadow[ ps ];
+                        h.pos = pos; h.d = out_d; h.limit = path_limit;
+                        h.contrib = v_mld( Tchild, v_mlf( bg, weight * diffuse_intensity ) );   /* k_hard_path's term for a miss */
+                        h.pixel = t.pixel; h.pad = 0;
+                        n_hs++;
+                    }
+                    else
+                    {
+                        atomicOr( &p_counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+                    }
+                }
                 /* hard path rays: the transition hit is finished by k_hard_path */
                 uint32_t hp = chunk_alloc( cs + 1, &p_counts[ QC_HARD_PATH ], hard );
                 if( hard )
@@ -988,7 +1054,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
 
         if( sub == 0 ) pixel_add( accum, sc.flags, t.pixel, v_mld( ldc( t.Tc ), lum ) );
     }
-    chunk_close( cs + 0, hard_cap, kill_hs );
+    chunk_close( cs + 0, hs_cap, kill_hs );
     chunk_close( cs + 1, hard_cap, kill_hp );
     chunk_close( cs + 2, child_cap, kill_ch );
     wave_stat_add( p_counts + QS_HARD_SHADOW, n_hs );
@@ -1025,10 +1091,22 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
             HardShadow r = recs[ first + ( threadIdx.x & 63 ) ];
             if( r.pixel != ACN_INVALID )
             {
-                bool occ;
+                bool occ = false;
                 ACN_LAP( PH_FETCH );
-                if constexpr( LDS ) occ = root_occluded( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, r.limit, &cnt );
-                else                occ = root_occluded( scene_view< PRUNE >( sc, sc.nodes ), sc.matter_root, r.pos, r.d, r.limit, &cnt );
+                /* a probe of a specular ray (probe_push) asks scene_s_trans_hit's question: the lights count as well.
+                 * One call site for both roots (the traversal with the CSG machine is in-line code). */
+                #pragma unroll 1
+                for( int k = 0; k < 2; k++ )
+                {
+                    const int root = k ? sc.matter_root : sc.light_root;
+                    const bool want = !occ && ( k == 1 || ( r.pad & 1u ) );
+                    if( __ballot( want ) == 0ull ) continue;
+                    if( want )
+                    {
+                        if constexpr( LDS ) occ = root_occluded( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), root, r.pos, r.d, r.limit, &cnt );
+                        else                occ = root_occluded( scene_view< PRUNE >( sc, sc.nodes ), root, r.pos, r.d, r.limit, &cnt );
+                    }
+                }
                 ACN_LAP( PH_ROOT_LEAF );
                 if( !occ ) { cnt.cost( ACN_F_DIRECT_TAIL ); pixel_add( accum, sc.flags, r.pixel, r.contrib ); }
                 ACN_LAP( PH_SHADE );

@@ -71,7 +71,7 @@ struct LaneWorker
  * host that changes its environment, and would let a value change between the concurrent lanes of one call) */
 struct Tunables
 {
-    size_t   workspace_mb = 32768;     /* ACN_WORKSPACE_MB: upper bound of the queue workspace of one handle (all its lanes) */
+    size_t   workspace_mb = 65536;     /* ACN_WORKSPACE_MB: upper bound of the queue workspace of one handle (all its lanes) */
     size_t   chunk = 0;                /* ACN_CHUNK: sample positions per pipeline run, 0 = derived from the queue capacity */
     int      lanes = 4;                /* ACN_LANES: concurrent pipeline runs of a large call */
     unsigned grid = 0;                 /* ACN_GRID: workgroups of the persistent kernels, 0 = 4 per compute unit */
@@ -830,12 +830,12 @@ extern "C" void acn_scene_free( acn_scene_handle* h )
 /* bytes of queue workspace per record of capacity */
 static size_t bytes_per_record()
 {
-    return sizeof( HitRec ) + sizeof( DTask ) + ACN_NCLASS * sizeof( uint32_t ) + sizeof( HardShadow ) + sizeof( HardPath ) + 2 * sizeof( RayTask );
+    return sizeof( HitRec ) + sizeof( DTask ) + ACN_NCLASS * sizeof( uint32_t ) + 2 * sizeof( HardShadow ) + sizeof( HardPath ) + 2 * sizeof( RayTask );
 }
 
 /* Queue capacities.  Only one chunk of positions is in flight per pipeline run, so the queues are sized for a chunk,
  * not for the call: room for the path-sample hits of ACN_CHUNK_TARGET positions (or of the whole call if it is smaller)
- * over two path levels, bounded by the handle's budget (ACN_WORKSPACE_MB, default 32 GiB, shared by its
+ * over two path levels, bounded by the handle's budget (ACN_WORKSPACE_MB, default 64 GiB, shared by its
  * lanes).  If the device cannot give that much, the request is halved until it fits: the chunk size follows the
  * capacity (launch_render), so a small workspace costs more chunks, not correctness. */
 #define ACN_CHUNK_TARGET ( ( size_t )1 << 18 )
@@ -862,7 +862,7 @@ static int ensure_workspace( acn_scene_handle* h, size_t n )
         grab( ( void** )&w.children, sizeof( HitRec ) * want );
         grab( ( void** )&w.tasks, sizeof( DTask ) * want );
         for( int k = 0; k < ACN_NCLASS; k++ ) grab( ( void** )&w.idx[ k ], sizeof( uint32_t ) * want );
-        grab( ( void** )&w.hard_shadow, sizeof( HardShadow ) * want );
+        grab( ( void** )&w.hard_shadow, sizeof( HardShadow ) * ( want < 0x7FFFFF80ull ? 2 * want : want ) );   /* LevelQ.hs_cap */
         grab( ( void** )&w.hard_path, sizeof( HardPath ) * want );
         for( int k = 0; k < 2; k++ ) grab( ( void** )&w.rays[ k ], sizeof( RayTask ) * want );
         grab( ( void** )&w.stacks, stack_bytes );
@@ -922,6 +922,7 @@ static LevelQ level_queues( const acn_scene_handle* h, int level )
     LevelQ q;
     q.tasks = w.tasks; for( int k = 0; k < ACN_NCLASS; k++ ) q.idx[ k ] = w.idx[ k ];
     q.task_cap = q.child_cap = q.hard_cap = q.ray_cap = w.cap;
+    q.hs_cap = w.cap < 0x7FFFFF80u ? 2 * w.cap : w.cap;
     q.children = w.children; q.hard_shadow = w.hard_shadow; q.hard_path = w.hard_path;
     q.rays[ 0 ] = w.rays[ 0 ]; q.rays[ 1 ] = w.rays[ 1 ];
     q.stacks = w.stacks; q.stack_cap = h->tun.stack_cap; q.stack_use = h->tun.stack_use;
@@ -1008,8 +1009,9 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
         if( c[ QC_TASKS ] > h->peak_tasks ) h->peak_tasks = c[ QC_TASKS ];
         if( c[ QC_CHILDREN ] > h->peak_children ) h->peak_children = c[ QC_CHILDREN ];
         /* the fullest queue of the chunk: what the next chunk's size is derived from */
-        const int q_slots[] = { QC_TASKS, QC_CLASS0, QC_CLASS0 + 1, QC_CLASS0 + 2, QC_CLASS0 + 3, QC_CHILDREN, QC_HARD_SHADOW, QC_HARD_PATH };
+        const int q_slots[] = { QC_TASKS, QC_CLASS0, QC_CLASS0 + 1, QC_CLASS0 + 2, QC_CLASS0 + 3, QC_CHILDREN, QC_HARD_PATH };
         for( int k : q_slots ) if( c[ k ] > *fullest ) *fullest = c[ k ];
+        if( c[ QC_HARD_SHADOW ] / 2 > *fullest ) *fullest = c[ QC_HARD_SHADOW ] / 2;   /* that queue has twice the slots (LevelQ.hs_cap) */
         for( int g = 0; g <= ACN_MAX_WALK_PASSES; g++ ) if( c[ QC_GEN + g ] > *fullest ) *fullest = c[ QC_GEN + g ];
         h->private_rays += c[ QS_PRIVATE_RAYS ];
     }

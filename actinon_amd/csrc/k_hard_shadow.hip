@@ -3,7 +3,7 @@
 #include "acn_launch.h"
 
 #define ACN_LHS_( C, L, P ) hipLaunchKernelGGL( ( k_hard_shadow< C, L, P > ), dim3( q.grid ), dim3( 256 ), lds_bytes, stream, \
-    ACN_SCENE_ARGS_OF( s ), ( const HardShadow* )q.hard_shadow, q.hard_cap, q.fetch_hard, q.counts, accum, counters )
+    ACN_SCENE_ARGS_OF( s ), ( const HardShadow* )q.hard_shadow, q.hs_cap, q.fetch_hard, q.counts, accum, counters )
 void acn_launch_hard_shadow( KernelFlags f, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
                              unsigned long long* accum, unsigned long long* counters )
 {
