@@ -267,6 +267,19 @@ DEV uint32_t wave_fetch( uint32_t* cursor, uint32_t want, uint32_t n, uint32_t* 
     return n - b < want ? n - b : want;
 }
 
+/* Batch size of a kernel's work fetch for an input of n items: the configured batch, but small enough that every wave of
+ * the grid comes back for work about eight times -- with one batch per wave the kernel ends when the wave that drew the
+ * expensive items is done (1/8 of a 1080p frame: k_shade 5.4 ms with batches of 16 steps, where the work is 1.2 ms).
+ * unit: items of one step of a wave. */
+DEV uint32_t balanced_batch( uint32_t n, uint32_t batch, uint32_t unit )
+{
+    const uint32_t waves = gridDim.x * ( blockDim.x >> 6 );
+    uint32_t b = n / ( waves * 8u );
+    b -= b % unit;
+    b = b < unit ? unit : b;
+    return b < batch ? b : batch;
+}
+
 /* the same in batches, one ahead: the wave owns the range [ cur, end ) of the input and, while it works that off, the
  * atomic that reserves its next batch is already in flight -- its 1-2 us round trip overlaps the work instead of
  * stalling the wave once per batch.  ( cur, end, more are the same in every lane; next is lane 0's. ) */
@@ -767,6 +780,7 @@ void k_shade_hits( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const HitRec* __restrict_
     n = n < rec_cap ? n : rec_cap;
     n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
     if( n == 0 ) return;
+    fetch_batch = balanced_batch( n, fetch_batch, 64u );
     ACN_SCENE_VIEW
     ACN_TASKQ_VIEW
     const ChunkP cs = ACN_CHUNKS_OF_WAVE;
@@ -846,6 +860,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
     uint32_t n_tasks = p_counts[ QC_CLASS0 + cls ];
     n_tasks = n_tasks < task_cap ? n_tasks : task_cap;
     n_tasks = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n_tasks );
+    fetch_batch = balanced_batch( n_tasks, fetch_batch, ( uint32_t )( 64 / LPT ) );
     uint32_t n_hs = 0, n_hp = 0, n_ch = 0;   /* statistics: records written by this lane */
     auto kill_hs = [ p_hard_shadow ]( uint32_t k ) { p_hard_shadow[ k ].pixel = ACN_INVALID; };
     auto kill_hp = [ p_hard_path ]( uint32_t k ) { p_hard_path[ k ].pixel = ACN_INVALID; };
@@ -1079,6 +1094,7 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
     uint32_t n = p_counts[ QC_HARD_SHADOW ];
     n = n < cap ? n : cap;
     n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
+    fetch_batch = balanced_batch( n, fetch_batch, 64u );
     FetchRange fr;
     range_init( fr, n > 0 );
     for( ;; )
@@ -1136,6 +1152,7 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
     uint32_t n = p_counts[ QC_HARD_PATH ];
     n = n < cap ? n : cap;
     n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
+    fetch_batch = balanced_batch( n, fetch_batch, 64u );
     uint32_t n_ch = 0;
     auto kill_ch = [ p_children ]( uint32_t k ) { p_children[ k ].pixel = ACN_INVALID; };
     FetchRange fr;
