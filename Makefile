@@ -11,7 +11,8 @@ WALK_WAVES  ?= 4
 # 1080p frame for the same speed, profiles/r02/NOTES.md); the hard-ray kernels are faster at 4
 TRACE_WAVES ?= 2
 EXTRA_DEFS ?=
-HIPFLAGS := $(EXTRA_DEFS) -DACN_SHADE_WAVES=$(SHADE_WAVES) -DACN_WALK_WAVES=$(WALK_WAVES) -DACN_TRACE_WAVES=$(TRACE_WAVES) -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Iinclude -Iactinon_amd/csrc -std=c++17 -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
+OPT ?= -O3
+HIPFLAGS := $(EXTRA_DEFS) -DACN_SHADE_WAVES=$(SHADE_WAVES) -DACN_WALK_WAVES=$(WALK_WAVES) -DACN_TRACE_WAVES=$(TRACE_WAVES) $(OPT) -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Iinclude -Iactinon_amd/csrc -std=c++17 -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
 
 all: hip host oracle cli
 
