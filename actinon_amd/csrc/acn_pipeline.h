@@ -163,6 +163,7 @@ enum
     QC_TASKS = 0, QC_CLASS0 = 1, QC_CHILDREN = 5, QC_FLAGS = 6, QC_HARD_SHADOW = 7, QC_HARD_PATH = 8,
     QC_CUR_HS = 9, QC_CUR_HP = 10, QC_CUR_HITS = 11, QC_CUR_SHADE0 = 20,   /* .. QC_CUR_SHADE0 + 3: one per size class */
     QS_WALK_RAYS = 12, QS_HARD_SHADOW = 13, QS_HARD_PATH = 14, QS_CHILDREN = 15, QS_TASKS = 16, QS_WALK_STEPS = 17, QS_PRIVATE_RAYS = 18,
+    QS_PROBES = 19,   /* specular rays that were answered by an any-hit probe instead of a walk (probe_push) */
     QC_GEN = 32, QC_CUR_GEN = QC_GEN + ACN_MAX_WALK_PASSES + 1,
     QC_N = 104
 };
@@ -401,6 +402,9 @@ DEV void probe_push( const TaskQ& tq, ChunkP pcs, bool want, V3 p, V3 d, double 
     uint32_t slot = chunk_alloc( pcs, &tq.counts[ QC_HARD_SHADOW ], want );
     if( want )
     {
+        /* statistics: one add per wave and call */
+        const unsigned long long m = __ballot( 1 );
+        if( ( int )( threadIdx.x & 63 ) == __ffsll( ( long long )m ) - 1 ) atomicAdd( &tq.counts[ QS_PROBES ], ( uint32_t )__popcll( m ) );
         if( slot < tq.probe_cap )
         {
             HardShadow& h = tq.probes[ slot ];

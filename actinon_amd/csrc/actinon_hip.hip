@@ -161,7 +161,7 @@ struct acn_scene_handle
     bool count_work = false;                   /* ACN_OPT_COUNT_WORK of the current call */
     uint32_t shard_rank = 0, shard_world = 1;  /* ACN_SHARD_SAMPLES of the current call */
     uint64_t launches[ 4 ] = { 0, 0, 0, 0 };   /* walk, shade, finalize, hard-ray kernels */
-    uint64_t hard_rays = 0, walk_steps = 0, walk_rays = 0, shade_hit_recs = 0, host_syncs = 0, private_rays = 0;
+    uint64_t hard_rays = 0, walk_steps = 0, walk_rays = 0, shade_hit_recs = 0, host_syncs = 0, private_rays = 0, probe_rays = 0;
     uint32_t flags_seen = 0;                   /* ACN_FLAG_* bits of the last call */
     double recs_per_pos = 0;                   /* learned: the fullest queue's records per sample position (chunk sizing) */
     uint64_t chunks = 0, retries = 0, levels = 0;
@@ -1014,6 +1014,7 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
         if( c[ QC_HARD_SHADOW ] / 2 > *fullest ) *fullest = c[ QC_HARD_SHADOW ] / 2;   /* that queue has twice the slots (LevelQ.hs_cap) */
         for( int g = 0; g <= ACN_MAX_WALK_PASSES; g++ ) if( c[ QC_GEN + g ] > *fullest ) *fullest = c[ QC_GEN + g ];
         h->private_rays += c[ QS_PRIVATE_RAYS ];
+        h->probe_rays += c[ QS_PROBES ];
     }
     return ACN_OK;
 }
@@ -1045,7 +1046,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     }
     h->events_used = 0;
     h->launches[ 0 ] = h->launches[ 1 ] = h->launches[ 2 ] = h->launches[ 3 ] = 0;
-    h->hard_rays = 0; h->walk_steps = 0; h->walk_rays = 0; h->shade_hit_recs = 0; h->host_syncs = 0; h->flags_seen = 0; h->private_rays = 0;
+    h->hard_rays = 0; h->walk_steps = 0; h->walk_rays = 0; h->shade_hit_recs = 0; h->host_syncs = 0; h->flags_seen = 0; h->private_rays = 0; h->probe_rays = 0;
     h->chunks = h->retries = h->levels = 0;
     h->peak_tasks = h->peak_children = 0;
     HIP_TRY( hipMemsetAsync( h->d_counters, 0, sizeof( unsigned long long ) * ACN_CNT_SLOTS, stream ) );
@@ -1274,7 +1275,7 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
     /* statistics of the call: sums / maxima over the lanes */
     h->events_used = 0;
     h->launches[ 0 ] = h->launches[ 1 ] = h->launches[ 2 ] = h->launches[ 3 ] = 0;
-    h->hard_rays = h->walk_steps = h->walk_rays = h->shade_hit_recs = h->host_syncs = h->private_rays = 0; h->flags_seen = 0;
+    h->hard_rays = h->walk_steps = h->walk_rays = h->shade_hit_recs = h->host_syncs = h->private_rays = h->probe_rays = 0; h->flags_seen = 0;
     h->chunks = h->retries = h->levels = 0;
     h->peak_tasks = h->peak_children = 0;
     for( int k = 0; k < lanes; k++ )
@@ -1283,7 +1284,7 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
         if( lane_count( n, lanes, k ) == 0 ) continue;
         for( int i = 0; i < 4; i++ ) h->launches[ i ] += l->launches[ i ];
         h->hard_rays += l->hard_rays; h->walk_steps += l->walk_steps; h->walk_rays += l->walk_rays; h->shade_hit_recs += l->shade_hit_recs;
-        h->host_syncs += l->host_syncs; h->flags_seen |= l->flags_seen; h->private_rays += l->private_rays;
+        h->host_syncs += l->host_syncs; h->flags_seen |= l->flags_seen; h->private_rays += l->private_rays; h->probe_rays += l->probe_rays;
         h->chunks += l->chunks; h->retries += l->retries;
         if( l->levels > h->levels ) h->levels = l->levels;
         h->peak_tasks += l->peak_tasks; h->peak_children += l->peak_children;
@@ -1447,7 +1448,7 @@ extern "C" int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms )
 
 extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
 {
-    if( !h || !out || n < 0 || n > 22 || !h->timed ) return fail( ACN_ERR_ARG, "no timed launch" );
+    if( !h || !out || n < 0 || n > 23 || !h->timed ) return fail( ACN_ERR_ARG, "no timed launch" );
     HIP_TRY( hipSetDevice( h->device ) );
     HIP_TRY( hipEventSynchronize( h->ev1 ) );
     double ms[ 4 ] = { 0, 0, 0, 0 };
@@ -1466,12 +1467,12 @@ extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
     }
     float total = 0;
     HIP_TRY( hipEventElapsedTime( &total, h->ev0, h->ev1 ) );
-    double v[ 22 ] = { ms[ 0 ], ms[ 1 ], ms[ 2 ], total, ( double )h->launches[ 0 ], ( double )h->launches[ 1 ], ( double )h->launches[ 2 ],
+    double v[ 23 ] = { ms[ 0 ], ms[ 1 ], ms[ 2 ], total, ( double )h->launches[ 0 ], ( double )h->launches[ 1 ], ( double )h->launches[ 2 ],
                        ( double )h->chunks, ( double )h->retries, ( double )h->levels, ( double )h->peak_tasks, ( double )h->peak_children,
                        ( double )queue_cap, ms[ 3 ], ( double )h->launches[ 3 ], ( double )h->hard_rays,
                        ( double )h->walk_rays, ( double )h->shade_hit_recs, ( double )h->host_syncs, ( double )h->walk_steps,
-                       ( double )h->flags_seen, ( double )h->private_rays };
-    for( int k = 0; k < n && k < 22; k++ ) out[ k ] = v[ k ];
+                       ( double )h->flags_seen, ( double )h->private_rays, ( double )h->probe_rays };
+    for( int k = 0; k < n && k < 23; k++ ) out[ k ] = v[ k ];
     return ACN_OK;
 }
 

@@ -284,9 +284,9 @@ class Handle:
         """Per-stage device time (ms) and pipeline statistics of the last render call."""
         names = ["walk_ms", "shade_ms", "finalize_ms", "total_ms", "walk_launches", "shade_launches", "finalize_launches",
                  "chunks", "retries", "levels", "peak_tasks", "peak_children", "queue_cap", "hard_ms", "hard_launches",
-                 "hard_rays", "walk_rays", "path_hits", "host_syncs", "walk_steps", "flags", "private_rays"]
-        buf = (C.c_double * 22)()
-        check(hip.acn_last_stage_ms(self.h, buf, 22), "acn_last_stage_ms")
+                 "hard_rays", "walk_rays", "path_hits", "host_syncs", "walk_steps", "flags", "private_rays", "probe_rays"]
+        buf = (C.c_double * 23)()
+        check(hip.acn_last_stage_ms(self.h, buf, 23), "acn_last_stage_ms")
         return dict(zip(names, [float(v) for v in buf]))
 
     def last_counters(self):

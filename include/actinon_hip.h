@@ -254,7 +254,8 @@ int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms );
  * included), [17] path-sample hits shaded (levels >= 1), [18] host synchronisations inside the pipeline (one per chunk),
  * [19] 64-ray steps of the walk kernel's waves ([16] / ( 64 * [19] ) is its lane occupancy), [20] ACN_FLAG_* bits seen
  * (8: a pixel contribution exceeded the fixed-point clamp of 16384), [21] rays the walk finished on the waves' private
- * stacks instead of in generation passes. n <= 22. */
+ * stacks instead of in generation passes, [22] specular rays whose radiance is zero on a hit (depth 0 or intensity below
+ * trace_min_intensity, src/scene.c:430) and that were therefore answered by an any-hit probe instead of a walk. n <= 23. */
 int acn_last_stage_ms( acn_scene_handle* h, double* out, int n );
 
 /* Work counters of the last render call (rays cast, node visits ...), see DESIGN.md: [0..7] events, [8] flop and

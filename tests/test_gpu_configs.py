@@ -208,3 +208,33 @@ def test_tile_shards_reassemble_bit_for_bit():
             cnt = A.hip.acn_shard_tile_count(n, rank, world)
             assert (gathered[rank, cnt:] == 0).all()
     h.close()
+
+
+def test_bench_two_ranks_on_one_gpu_match_one_rank(tmp_path):
+    """bench.py's N > 1 path end to end on real hardware: two processes (ranks) share the one GPU of the box
+    (ACN_BENCH_SINGLE_DEVICE=1: gloo instead of RCCL between them), each renders its tiles through
+    acn_render_main_pass_shard_dev, the parts are all-gathered, rank 0 unpacks, resolves and writes the image -- which must
+    be the image of a one-rank run, byte for byte."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, ACN_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = tmp_path / "two.pnm"
+    one = tmp_path / "one.pnm"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--workload", "smoke", "--no-cpu-baseline", "--save-image", str(two)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "all_gather" in json.dumps(line["config"])
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--workload", "smoke",
+                        "--no-cpu-baseline", "--save-image", str(one)], env=dict(os.environ), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert two.read_bytes() == one.read_bytes()

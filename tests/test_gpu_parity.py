@@ -105,6 +105,21 @@ def test_work_counters_match_oracle_exactly(oracle):
     assert 0.97 * c["transc"] <= g["transcendentals"] <= c["transc"], (g["transcendentals"], c["transc"])
 
 
+def test_probe_rays_replace_walks_without_changing_counts(oracle):
+    """Specular children that scene_s_lum would answer with zero (src/scene.c:430) are any-hit probes, not walks: a good
+    part of the wine glass's rays, and the sum of both is what the pipeline walked when every ray was a walk -- the number
+    of scene_s_trans_hit calls of the oracle stays exactly matched (test_work_counters_match_oracle_exactly)."""
+    sc, flat = S.build("wine_glass_c2")
+    pos = S.positions(flat)
+    h = A.Handle(flat)
+    gpu = h.render_positions(pos, linear=True)
+    st = h.last_stages()
+    h.close()
+    assert st["probe_rays"] > 0.2 * st["walk_rays"], st
+    cpu = oracle.render_positions(flat, pos, linear=True)
+    assert np.abs(gpu - cpu).max() <= TOL
+
+
 def test_edge_cases(oracle):
     # empty scene -> background everywhere; zero positions; sub-pixel / off-raster positions
     sc = A.Scene()
