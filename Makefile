@@ -22,7 +22,7 @@ oracle: oracle/libacn_oracle.so oracle/libacn_oracle_libm.so
 cli: actinon_amd/bin/actinon_hip
 
 # one object per kernel family: `make -j` compiles them side by side (acn_launch.h)
-HIP_UNITS := actinon_hip k_shade_64 k_shade_16 k_shade_4 k_shade_1 k_walk_lds k_walk_glb k_walk_count k_hard_shadow k_hard_path
+HIP_UNITS := actinon_hip k_shade_64 k_shade_16 k_shade_4 k_shade_1 k_walk_lds k_walk_glb k_walk_count k_walk_count_prune k_hard_shadow k_hard_path
 HIP_OBJS  := $(addprefix $(BUILD)/,$(addsuffix .o,$(HIP_UNITS)))
 $(BUILD)/%.o: actinon_amd/csrc/%.hip $(wildcard actinon_amd/csrc/*.h) include/actinon_hip.h
 	@mkdir -p $(BUILD)
@@ -38,11 +38,14 @@ actinon_amd/bin/actinon_hip: tools/actinon_hip.c include/acn_interp.h $(LIBDIR)/
 	@mkdir -p actinon_amd/bin
 	$(CC) $(CFLAGS) -o $@ tools/actinon_hip.c -L$(LIBDIR) -lactinon_host -lactinon_hip -lm -Wl,-rpath,'$$ORIGIN/../lib'
 
+# the two prebuilt oracles travel to the GPU box: a portable ISA level (AVX2 + FMA), not the build container's -march=native
+# (bench.py compiles a third build on the box itself with the reference's flags for the CPU baseline)
+ORACLE_MARCH ?= x86-64-v3
 oracle/libacn_oracle.so: oracle/acn_oracle.c oracle/acn_oracle.h actinon_amd/csrc/acn_detmath.h actinon_amd/csrc/acn_costs.h include/actinon_hip.h
-	$(CC) $(CFLAGS) -march=native -Ioracle -shared -o $@ oracle/acn_oracle.c -lm -lpthread
+	$(CC) $(CFLAGS) -march=$(ORACLE_MARCH) -Ioracle -shared -o $@ oracle/acn_oracle.c -lm -lpthread
 
 oracle/libacn_oracle_libm.so: oracle/acn_oracle.c oracle/acn_oracle.h actinon_amd/csrc/acn_costs.h include/actinon_hip.h
-	$(CC) $(CFLAGS) -march=native -DACN_ORACLE_LIBM -Ioracle -shared -o $@ oracle/acn_oracle.c -lm -lpthread
+	$(CC) $(CFLAGS) -march=$(ORACLE_MARCH) -DACN_ORACLE_LIBM -Ioracle -shared -o $@ oracle/acn_oracle.c -lm -lpthread
 
 clean:
 	rm -rf build; rm -f $(LIBDIR)/*.so oracle/*.so actinon_amd/bin/actinon_hip

@@ -48,7 +48,7 @@ class FlatScene(C.Structure):
 
 
 class RenderOpts(C.Structure):
-    _fields_ = [("flags", C.c_uint32), ("reserved", C.c_int32), ("cancel", C.POINTER(C.c_int)), ("stream", C.c_void_p),
+    _fields_ = [("flags", C.c_uint32), ("struct_size", C.c_uint32), ("cancel", C.POINTER(C.c_int)), ("stream", C.c_void_p),
                 ("shard_mode", C.c_uint32), ("shard_rank", C.c_uint32), ("shard_world", C.c_uint32), ("reserved2", C.c_uint32)]
 
 

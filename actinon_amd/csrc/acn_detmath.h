@@ -149,33 +149,26 @@ ACN_HD double acn_acos( double x )
         if( x == -1.0 ) return pi + 2.0 * pio2_lo;
         return ( x - x ) / ( x - x ); /* nan */
     }
-    if( ax < 0.5 )
-    {
-        if( ax < 6.938893903907228e-18 ) return pio2_hi + pio2_lo; /* 2^-57 */
-        double z = x * x;
-        double p = z * ( pS0 + z * ( pS1 + z * ( pS2 + z * ( pS3 + z * ( pS4 + z * pS5 ) ) ) ) );
-        double q = 1.0 + z * ( qS1 + z * ( qS2 + z * ( qS3 + z * qS4 ) ) );
-        double r = p / q;
-        return pio2_hi - ( x - ( pio2_lo - x * r ) );
-    }
+    /* The three ranges of e_acos.c share one evaluation of the rational term: z is chosen per range, p( z ) / q( z ) and --
+     * for the two outer ranges -- sqrt( z ) are computed once.  Per argument the operations and their order are those of
+     * the three separate branches (identical bits); a wavefront whose lanes fall into different ranges (the cosines of
+     * the Oren-Nayar term do) runs the 11 multiply-adds and the division once instead of up to three times. */
+    const int small = ax < 0.5;
+    if( small && ax < 6.938893903907228e-18 ) return pio2_hi + pio2_lo; /* 2^-57 */
+    double z = small ? x * x : ( x < 0 ? ( 1.0 + x ) * 0.5 : ( 1.0 - x ) * 0.5 );
+    double p = z * ( pS0 + z * ( pS1 + z * ( pS2 + z * ( pS3 + z * ( pS4 + z * pS5 ) ) ) ) );
+    double q = 1.0 + z * ( qS1 + z * ( qS2 + z * ( qS3 + z * qS4 ) ) );
+    double r = p / q;
+    if( small ) return pio2_hi - ( x - ( pio2_lo - x * r ) );
+    double s = acn_sqrt( z );
     if( x < 0 )
     {
-        double z = ( 1.0 + x ) * 0.5;
-        double p = z * ( pS0 + z * ( pS1 + z * ( pS2 + z * ( pS3 + z * ( pS4 + z * pS5 ) ) ) ) );
-        double q = 1.0 + z * ( qS1 + z * ( qS2 + z * ( qS3 + z * qS4 ) ) );
-        double s = acn_sqrt( z );
-        double r = p / q;
         double w = r * s - pio2_lo;
         return pi - 2.0 * ( s + w );
     }
     {
-        double z  = ( 1.0 - x ) * 0.5;
-        double s  = acn_sqrt( z );
         double df = acn_bits_f64( acn_f64_bits( s ) & 0xFFFFFFFF00000000ull );
         double c  = ( z - df * df ) / ( s + df );
-        double p  = z * ( pS0 + z * ( pS1 + z * ( pS2 + z * ( pS3 + z * ( pS4 + z * pS5 ) ) ) ) );
-        double q  = 1.0 + z * ( qS1 + z * ( qS2 + z * ( qS3 + z * qS4 ) ) );
-        double r  = p / q;
         double w  = r * s + c;
         return 2.0 * ( df + w );
     }

@@ -17,7 +17,8 @@ struct SceneArgs
     const acn_texture* textures;
 };
 
-/* variant selection: instrumented kernels (count) never carry prune programs */
+/* variant selection.  The instrumented kernels (count) exist with and without the prune programs / in-line simple
+ * compounds as well, so that a counted pass walks the traversal the timed pass walks */
 struct KernelFlags { bool count, leaf_lights, lds_nodes, prune; };
 
 /* the queues of one pipeline run (a handle's or a lane's workspace) as the kernels of path level L see them:
@@ -75,8 +76,8 @@ void acn_launch_hard_path( KernelFlags f, const LevelQ& q, size_t lds_bytes, hip
 #define ACN_DEFINE_LAUNCH_SHADE( NAME, LPT, CLS ) \
 void NAME( KernelFlags f, const LevelQ& q, hipStream_t stream, const SceneArgs& s, unsigned long long* accum, unsigned long long* counters ) \
 { \
-    /* the prune-program variants exist for the uninstrumented kernels only; count_work runs the plain ones */ \
-    if( f.count )      { if( f.leaf_lights ) ACN_LS_( LPT, CLS, true, true, false );  else ACN_LS_( LPT, CLS, true, false, false ); } \
+    if( f.count && f.prune ) { if( f.leaf_lights ) ACN_LS_( LPT, CLS, true, true, true );  else ACN_LS_( LPT, CLS, true, false, true ); } \
+    else if( f.count ) { if( f.leaf_lights ) ACN_LS_( LPT, CLS, true, true, false );  else ACN_LS_( LPT, CLS, true, false, false ); } \
     else if( f.prune ) { if( f.leaf_lights ) ACN_LS_( LPT, CLS, false, true, true );  else ACN_LS_( LPT, CLS, false, false, true ); } \
     else               { if( f.leaf_lights ) ACN_LS_( LPT, CLS, false, true, false ); else ACN_LS_( LPT, CLS, false, false, false ); } \
 }

@@ -890,6 +890,8 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
         if( on_b > 0 ) acn_sincos( theta_i, &sin_i, &cos_i );
         uint64_t rv = t.rv;
         V3 lum = mk( 0, 0, 0 );   /* lum_l of scene.c:539, identical in all lanes of the group after each reduction */
+        ACN_LAP( PH_FETCH );      /* diagnostic build: k_shade books 10 task fetch / set-up, 4 cap sample, 5 light hit, 6 Oren-Nayar,
+                                     7 occlusion, 8 queue appends and sums, 9 path sample, 11 path transition hit */
 
         /* ---- direct light, scene.c:542-581 ---- */
         NodeP light = &sc.nodes[ sc.light_root ];
@@ -930,10 +932,12 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 cnt.cost( ACN_F_CAP_SAMPLE, ACN_T_CAP_SAMPLE );
                 V3 out_d = m_mlv( src_con, v_random_sphere_cap( &r, cyl_hgt ) );
                 double weight = v_mlv( out_d, surface_d );
+                ACN_LAP( PH_M_LEAF );
                 if( weight <= 0 ) continue;
                 double a;
                 if( LEAF_LIGHTS ) a = leaf_element_hit< false >( light_src, light_src->type, pos, out_d, nullptr, &cnt );
                 else a = light_hit_call( sc, light_idx, pos, out_d, &cnt );
+                ACN_LAP( PH_M_PAIR );
                 if( a >= F3_INF ) continue;
                 if( on_b > 0 ) { cnt.cost( ACN_F_OREN_NAYAR, ACN_T_OREN_NAYAR ); weight = oren_nayar_weight_pre( weight, theta_i, sin_i, cos_i, on_a, on_b, out_d, surface_d, ray_projection ); }
                 cnt.inc( CNT_SHADOW_RAY );
@@ -941,7 +945,9 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 double diff_sqr = v_diff_sqr( hit_pos, light_pos );
                 double local_intensity = ( diff_sqr > 0 ) ? ( radiance / diff_sqr ) : F3_MAG;
                 double c = local_intensity * weight * diffuse_intensity;
+                ACN_LAP( PH_M_FRAME );
                 int occ = root_occluded_fast( scp, sc.matter_root, pos, out_d, a, &cnt );
+                ACN_LAP( PH_M_SIDE );
                 if( occ == 0 ) { s += c; cnt.cost( ACN_F_DIRECT_TAIL ); }
                 /* hard shadow rays: appended to the queue of k_hard_shadow, which adds c itself if unoccluded */
                 uint32_t hs = chunk_alloc( cs + 0, &p_counts[ QC_HARD_SHADOW ], occ == 2 );
@@ -967,6 +973,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
             s = group_sum< LPT >( s );
             double f = s * ( 2.0 * cyl_hgt / direct_samples );
             lum.x += light_color.x * f; lum.y += light_color.y * f; lum.z += light_color.z * f;
+            ACN_LAP( PH_SHADE );
         }
 
         /* ---- path tracing, scene.c:584-621 ---- */
@@ -1005,7 +1012,9 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 {
                     if( on_b > 0 ) { cnt.cost( ACN_F_OREN_NAYAR, ACN_T_OREN_NAYAR ); weight = oren_nayar_weight_pre( weight, theta_i, sin_i, cos_i, on_a, on_b, out_d, surface_d, ray_projection ); }
                     cnt.cost( ACN_F_PATH_TAIL );
+                    ACN_LAP( PH_COMPOUND );
                     a = root_trans_hit_fast( scp, sc.matter_root, pos, out_d, &trans, &hard, &cnt );
+                    ACN_LAP( PH_TAIL );
                 }
                 bool hit = live && !hard && a < sc.prm.max_path_length;
                 if( live && !hard && !hit ) bsum += weight * diffuse_intensity;
@@ -1072,6 +1081,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
         }
 
         if( sub == 0 ) pixel_add( accum, sc.flags, t.pixel, v_mld( ldc( t.Tc ), lum ) );
+        ACN_LAP( PH_SHADE );
     }
     chunk_close( cs + 0, hs_cap, kill_hs );
     chunk_close( cs + 1, hard_cap, kill_hp );

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstddef>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -71,11 +72,13 @@ struct LaneWorker
  * host that changes its environment, and would let a value change between the concurrent lanes of one call) */
 struct Tunables
 {
-    size_t   workspace_mb = 65536;     /* ACN_WORKSPACE_MB: upper bound of the queue workspace of one handle (all its lanes) */
+    size_t   workspace_mb = 0;         /* ACN_WORKSPACE_MB: upper bound of the queue workspace of one handle (all its lanes); 0: 8 GiB or a
+                                          quarter of the device memory that is free at upload, whichever is less */
     size_t   chunk = 0;                /* ACN_CHUNK: sample positions per pipeline run, 0 = derived from the queue capacity */
     int      lanes = 4;                /* ACN_LANES: concurrent pipeline runs of a large call */
     unsigned grid = 0;                 /* ACN_GRID: workgroups of the persistent kernels, 0 = 4 per compute unit */
     unsigned shade_grid = 0;           /* ACN_SHADE_GRID: workgroups of k_shade, 0 = 4 per compute unit */
+    unsigned walk_grid = 0;            /* ACN_WALK_GRID: workgroups of k_walk (256 VGPRs: two of its waves fill a SIMD's register file), 0 = as ACN_GRID */
     uint32_t stack_cap = 512;          /* ACN_STACK_CAP: private ray slots per k_walk wave */
     uint32_t fetch_walk = 64;          /* ACN_FETCH_WALK: fresh rays a k_walk wave reserves per cursor atomic */
     uint32_t walk_passes = 12;         /* ACN_WALK_PASSES: launches of k_walk per path level (the last one finishes whatever is left) */
@@ -93,6 +96,7 @@ struct Tunables
         if( const char* e = getenv( "ACN_LANES" ) ) lanes = atoi( e );
         if( const char* e = getenv( "ACN_GRID" ) ) grid = ( unsigned )atoi( e );
         if( const char* e = getenv( "ACN_SHADE_GRID" ) ) shade_grid = ( unsigned )atoi( e );
+        if( const char* e = getenv( "ACN_WALK_GRID" ) ) walk_grid = ( unsigned )atoi( e );
         if( const char* e = getenv( "ACN_STACK_CAP" ) ) stack_cap = ( uint32_t )atoll( e );
         if( const char* e = getenv( "ACN_TEST_STACK_USE" ) ) stack_use = ( uint32_t )atoll( e );
         if( const char* e = getenv( "ACN_FETCH_WALK" ) ) fetch_walk = ( uint32_t )atoll( e );
@@ -125,8 +129,14 @@ struct Workspace
     HardPath*   hard_path = nullptr;
     RayTask*    rays[ 2 ] = { nullptr, nullptr };
     RayTask*    stacks = nullptr;   size_t stack_waves = 0;
-    uint32_t    cap = 0;            /* records per queue */
+    uint32_t    cap[ 5 ] = { 0, 0, 0, 0, 0 };   /* records per queue, WQ_* */
+    size_t      bytes = 0;          /* device memory of the queues and stacks */
 };
+/* the queues of a pipeline run.  Each is sized from its OWN demand per sample position (learned, below): on the wine glass a
+ * position leaves 15 deferred shadow rays but 2 shading points, and one common capacity -- the former layout -- made every
+ * queue as large as the fullest one needs (64 GiB for a 1080p frame of which 7 % were used). */
+enum { WQ_TASKS = 0, WQ_CHILDREN, WQ_HARD_SHADOW, WQ_HARD_PATH, WQ_RAYS, WQ_N };
+static const size_t wq_bytes[ WQ_N ] = { sizeof( DTask ) + ACN_NCLASS * sizeof( uint32_t ), sizeof( HitRec ), sizeof( HardShadow ), sizeof( HardPath ), 2 * sizeof( RayTask ) };
 
 struct acn_scene_handle
 {
@@ -146,6 +156,7 @@ struct acn_scene_handle
     Tunables tun;
     unsigned cus = 256;                        /* compute units of the device */
     unsigned grid = 1024, shade_grid = 1024;   /* workgroups of the persistent kernels / of k_shade */
+    unsigned walk_grid = 1024;                 /* ... of k_walk */
     int n_levels = 1;                          /* path levels of the scene's trace_depth */
     /* workspace of the wavefront pipeline */
     Workspace ws;
@@ -163,9 +174,13 @@ struct acn_scene_handle
     uint64_t launches[ 4 ] = { 0, 0, 0, 0 };   /* walk, shade, finalize, hard-ray kernels */
     uint64_t hard_rays = 0, walk_steps = 0, walk_rays = 0, shade_hit_recs = 0, host_syncs = 0, private_rays = 0, probe_rays = 0;
     uint32_t flags_seen = 0;                   /* ACN_FLAG_* bits of the last call */
-    double recs_per_pos = 0;                   /* learned: the fullest queue's records per sample position (chunk sizing) */
+    uint32_t rate_cnt = 0;                     /* positions of the chunk the rates were taken from */
+    double rate[ 5 ] = { 0, 0, 0, 0, 0 };      /* learned: records per sample position a chunk leaves in each queue (WQ_*); 0: not known yet */
+    size_t workspace_budget = 0;               /* bytes this handle's queues may take (all lanes together) */
     uint64_t chunks = 0, retries = 0, levels = 0;
     uint64_t peak_tasks = 0, peak_children = 0;
+    uint32_t walk_passes_seen[ ACN_MAX_PATH_LEVELS + 1 ] = { 0, 0, 0, 0, 0, 0 };   /* learned: passes of a level that had input in the last chunk (0: not known yet) */
+    unsigned long long* d_counters_keep = nullptr;   /* the work counters as they were before the current chunk (restored when it is redone) */
     /* concurrent lanes (render_lanes): clones of this handle that share the resident scene and own a stream and a
      * workspace each */
     bool is_lane = false;
@@ -177,6 +192,7 @@ struct acn_scene_handle
     double* d_shard_pos = nullptr; size_t shard_pos_cap = 0;                                /* acn_render_main_pass_shard_dev: the rank's positions */
     std::string lane_error;
     bool used_lanes = false;                   /* the last render call ran through the lanes: statistics are their sums */
+    int  lanes_used = 0;                       /* ... the first lanes_used of them */
 };
 #define ACN_LEVEL_BLOCKS ( ACN_MAX_PATH_LEVELS + 1 )
 
@@ -457,6 +473,13 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     h->max_csg_depth = max_csg;
     h->tun.read();
     {
+        /* workspace budget of the handle: ACN_WORKSPACE_MB, or 8 GiB / a quarter of the free device memory */
+        size_t free_b = 0, total_b = 0;
+        if( hipMemGetInfo( &free_b, &total_b ) != hipSuccess ) free_b = ( size_t )32 << 30;
+        h->workspace_budget = h->tun.workspace_mb ? h->tun.workspace_mb * 1024 * 1024 : ( ( size_t )8 << 30 );
+        if( !h->tun.workspace_mb && h->workspace_budget > free_b / 4 ) h->workspace_budget = free_b / 4;
+    }
+    {
         int cus = 0;
         if( hipDeviceGetAttribute( &cus, hipDeviceAttributeMultiprocessorCount, device ) != hipSuccess || cus <= 0 ) cus = 256;
         /* persistent grids.  A call that runs alone on its stream: 4 workgroups of 256 lanes per CU, what fits of the
@@ -466,6 +489,7 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
         h->cus = ( unsigned )cus;
         h->grid = h->tun.grid ? h->tun.grid : ( unsigned )cus * 4u;
         h->shade_grid = h->tun.shade_grid ? h->tun.shade_grid : ( unsigned )cus * 4u;
+        h->walk_grid = h->tun.walk_grid ? h->tun.walk_grid : h->grid;
         /* path levels: level L shades hits at depth trace_depth - 10 L and spawns the next one while that is > 10 (scene.c:584) */
         uint64_t td = scene->params.trace_depth;
         h->n_levels = scene->params.path_samples && td > 10 ? 1 + ( int )( ( td - 10 + 9 ) / 10 ) : 1;
@@ -729,6 +753,7 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     if( scene->n_textures ) HIP_TRY_H( hipMemcpy( h->d_textures, scene->textures, sizeof( acn_texture ) * scene->n_textures, hipMemcpyHostToDevice ) );
     HIP_TRY_H( hipMalloc( &h->d_counters, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
     HIP_TRY_H( hipMemset( h->d_counters, 0, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
+    HIP_TRY_H( hipMalloc( &h->d_counters_keep, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
     HIP_TRY_H( hipMalloc( &h->d_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
     HIP_TRY_H( hipHostMalloc( &h->h_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
     HIP_TRY_H( hipMemcpy( h->d_nodes, nodes.data(), sizeof( GNode ) * scene->n_nodes, hipMemcpyHostToDevice ) );
@@ -820,6 +845,7 @@ extern "C" void acn_scene_free( acn_scene_handle* h )
         if( h->d_sc_table ) hipFree( h->d_sc_table );
     }
     if( h->d_counters ) hipFree( h->d_counters );
+    if( h->d_counters_keep ) hipFree( h->d_counters_keep );
     for( auto& e : h->events ) { hipEventDestroy( e.a ); hipEventDestroy( e.b ); }
     if( h->ev0 ) hipEventDestroy( h->ev0 );
     if( h->ev1 ) hipEventDestroy( h->ev1 );
@@ -827,52 +853,91 @@ extern "C" void acn_scene_free( acn_scene_handle* h )
     delete h;
 }
 
-/* bytes of queue workspace per record of capacity */
-static size_t bytes_per_record()
+/* Queue capacities.  Only one chunk of positions is in flight per pipeline run, so the queues are sized for a chunk, not
+ * for the call, and each queue for its own demand:
+ *   - rates unknown (first call on a handle): a small uniform starter set; the first chunk of the call is small, teaches
+ *     the rates (render_chunk) and launch_render comes back here;
+ *   - rates known: room for as many positions as the call has (at most ACN_CHUNK_TARGET) at 1 / 0.7 of the learned rates,
+ *     scaled down to the handle's budget (ACN_WORKSPACE_MB; default 8 GiB or a quarter of the free device memory) if that is
+ *     less.  The chunk size follows the capacities (launch_render), so a small workspace costs more chunks, not
+ *     correctness; if hipMalloc refuses, the request is halved until it fits. */
+#define ACN_CHUNK_TARGET ( ( size_t )1 << 20 )
+#define ACN_STARTER_RECORDS ( ( size_t )1 << 20 )
+static double f_max_host( double a, double b ) { return a > b ? a : b; }
+static bool rates_known( const acn_scene_handle* h ) { return h->rate[ WQ_TASKS ] > 0 || h->rate[ WQ_RAYS ] > 0 || h->rate[ WQ_HARD_SHADOW ] > 0; }
+
+/* positions a chunk may have so that every queue stays below 70 % of its capacity */
+static size_t chunk_for_caps( const acn_scene_handle* h )
 {
-    return sizeof( HitRec ) + sizeof( DTask ) + ACN_NCLASS * sizeof( uint32_t ) + 2 * sizeof( HardShadow ) + sizeof( HardPath ) + 2 * sizeof( RayTask );
+    double chunk = 2.0e9;
+    for( int q = 0; q < WQ_N; q++ )
+    {
+        const double r = h->rate[ q ] > 1e-3 ? h->rate[ q ] : 1e-3;
+        const double c = 0.7 * ( double )h->ws.cap[ q ] / r;
+        if( c < chunk ) chunk = c;
+    }
+    return chunk < 64 ? 64 : ( size_t )chunk;
 }
 
-/* Queue capacities.  Only one chunk of positions is in flight per pipeline run, so the queues are sized for a chunk,
- * not for the call: room for the path-sample hits of ACN_CHUNK_TARGET positions (or of the whole call if it is smaller)
- * over two path levels, bounded by the handle's budget (ACN_WORKSPACE_MB, default 64 GiB, shared by its
- * lanes).  If the device cannot give that much, the request is halved until it fits: the chunk size follows the
- * capacity (launch_render), so a small workspace costs more chunks, not correctness. */
-#define ACN_CHUNK_TARGET ( ( size_t )1 << 18 )
 static int ensure_workspace( acn_scene_handle* h, size_t n )
 {
     Workspace& w = h->ws;
-    size_t budget = h->tun.workspace_mb * 1024 * 1024 / h->budget_div;
-    size_t stack_waves = ( size_t )h->grid * 4;
-    size_t stack_bytes = stack_waves * h->tun.stack_cap * sizeof( RayTask );
-    size_t max_recs = budget > stack_bytes ? ( budget - stack_bytes ) / bytes_per_record() : 0;
-    size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
-    size_t positions = n < ACN_CHUNK_TARGET ? n : ACN_CHUNK_TARGET;
-    /* the second path level multiplies the hits of the first by path_samples * intensity again (scene.c:593-610) */
-    size_t want = positions * ( s + 2 ) * ( s > 16 ? s / 16 : 1 ) + 65536;
-    if( want > max_recs ) want = max_recs;
-    if( want < 65536 ) want = 65536;
-    if( want > 0xFFFFFF00ull ) want = 0xFFFFFF00ull;
-    if( w.cap >= want && w.stack_waves >= stack_waves ) return ACN_OK;
+    const size_t budget = h->workspace_budget / h->budget_div;
+    const size_t stack_waves = ( size_t )( h->walk_grid > h->grid ? h->walk_grid : h->grid ) * 4;
+    const size_t stack_bytes = stack_waves * h->tun.stack_cap * sizeof( RayTask );
+    size_t want[ WQ_N ];
+    if( !rates_known( h ) )
+    {
+        /* starter set: what a first chunk of a few thousand positions needs at the old quadratic guess, at most 2^20 records */
+        const size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
+        size_t recs = ( n < 8192 ? n : 8192 ) * ( s + 2 ) * ( s > 16 ? s / 16 : 1 ) + 65536;
+        if( recs > ACN_STARTER_RECORDS ) recs = ACN_STARTER_RECORDS;
+        size_t per_rec = wq_bytes[ WQ_HARD_SHADOW ];
+        for( int q = 0; q < WQ_N; q++ ) per_rec += wq_bytes[ q ];
+        const size_t max_recs = budget > stack_bytes ? ( budget - stack_bytes ) / per_rec : 0;
+        if( recs > max_recs ) recs = max_recs;
+        for( int q = 0; q < WQ_N; q++ ) want[ q ] = recs;
+        want[ WQ_HARD_SHADOW ] = 2 * recs;
+    }
+    else
+    {
+        double positions = ( double )( n < ACN_CHUNK_TARGET ? n : ACN_CHUNK_TARGET );
+        double bytes = 0;
+        for( int q = 0; q < WQ_N; q++ ) bytes += ( h->rate[ q ] * positions / 0.7 + 65536.0 ) * ( double )wq_bytes[ q ];
+        const double room = budget > stack_bytes ? ( double )( budget - stack_bytes ) : 0.0;
+        if( bytes > room ) positions *= room / bytes;
+        for( int q = 0; q < WQ_N; q++ )
+        {
+            double c = h->rate[ q ] * positions / 0.7 + 65536.0;
+            want[ q ] = c > 4.0e9 ? 0xFFFFFF00ull : ( size_t )c;
+        }
+    }
+    for( int q = 0; q < WQ_N; q++ ) { if( want[ q ] < 65536 ) want[ q ] = 65536; if( want[ q ] > 0xFFFFFF00ull ) want[ q ] = 0xFFFFFF00ull; }
+    /* keep what is there while it is large enough (within 20 %: the rates move a little from call to call) */
+    bool fits = w.stack_waves >= stack_waves;
+    for( int q = 0; q < WQ_N; q++ ) if( ( double )w.cap[ q ] < 0.8 * ( double )want[ q ] ) fits = false;
+    if( fits ) return ACN_OK;
     free_workspace( h );
     for( ;; )
     {
         hipError_t e = hipSuccess;
-        auto grab = [ & ]( void** p, size_t bytes ) { if( e == hipSuccess ) e = hipMalloc( p, bytes ); };
-        grab( ( void** )&w.children, sizeof( HitRec ) * want );
-        grab( ( void** )&w.tasks, sizeof( DTask ) * want );
-        for( int k = 0; k < ACN_NCLASS; k++ ) grab( ( void** )&w.idx[ k ], sizeof( uint32_t ) * want );
-        grab( ( void** )&w.hard_shadow, sizeof( HardShadow ) * ( want < 0x7FFFFF80ull ? 2 * want : want ) );   /* LevelQ.hs_cap */
-        grab( ( void** )&w.hard_path, sizeof( HardPath ) * want );
-        for( int k = 0; k < 2; k++ ) grab( ( void** )&w.rays[ k ], sizeof( RayTask ) * want );
+        size_t total = 0;
+        auto grab = [ & ]( void** p, size_t bytes ) { if( e == hipSuccess ) { e = hipMalloc( p, bytes ); total += bytes; } };
+        grab( ( void** )&w.children, sizeof( HitRec ) * want[ WQ_CHILDREN ] );
+        grab( ( void** )&w.tasks, sizeof( DTask ) * want[ WQ_TASKS ] );
+        for( int k = 0; k < ACN_NCLASS; k++ ) grab( ( void** )&w.idx[ k ], sizeof( uint32_t ) * want[ WQ_TASKS ] );
+        grab( ( void** )&w.hard_shadow, sizeof( HardShadow ) * want[ WQ_HARD_SHADOW ] );
+        grab( ( void** )&w.hard_path, sizeof( HardPath ) * want[ WQ_HARD_PATH ] );
+        for( int k = 0; k < 2; k++ ) grab( ( void** )&w.rays[ k ], sizeof( RayTask ) * want[ WQ_RAYS ] );
         grab( ( void** )&w.stacks, stack_bytes );
-        if( e == hipSuccess ) break;
+        if( e == hipSuccess ) { w.bytes = total; break; }
         ( void )hipGetLastError();
         free_workspace( h );
-        if( want <= 65536 ) return fail( ACN_ERR_DEVICE, std::string( "queue workspace: " ) + hipGetErrorString( e ) );
-        want = want / 2 < 65536 ? 65536 : want / 2;
+        bool floor = true;
+        for( int q = 0; q < WQ_N; q++ ) { if( want[ q ] > 65536 ) floor = false; want[ q ] = want[ q ] / 2 < 65536 ? 65536 : want[ q ] / 2; }
+        if( floor ) return fail( ACN_ERR_DEVICE, std::string( "queue workspace: " ) + hipGetErrorString( e ) );
     }
-    w.cap = ( uint32_t )want;
+    for( int q = 0; q < WQ_N; q++ ) w.cap[ q ] = ( uint32_t )want[ q ];
     w.stack_waves = stack_waves;
     return ACN_OK;
 }
@@ -921,8 +986,8 @@ static LevelQ level_queues( const acn_scene_handle* h, int level )
     const Workspace& w = h->ws;
     LevelQ q;
     q.tasks = w.tasks; for( int k = 0; k < ACN_NCLASS; k++ ) q.idx[ k ] = w.idx[ k ];
-    q.task_cap = q.child_cap = q.hard_cap = q.ray_cap = w.cap;
-    q.hs_cap = w.cap < 0x7FFFFF80u ? 2 * w.cap : w.cap;
+    q.task_cap = w.cap[ WQ_TASKS ]; q.child_cap = w.cap[ WQ_CHILDREN ]; q.hs_cap = w.cap[ WQ_HARD_SHADOW ]; q.hard_cap = w.cap[ WQ_HARD_PATH ];
+    q.ray_cap = w.cap[ WQ_RAYS ];
     q.children = w.children; q.hard_shadow = w.hard_shadow; q.hard_path = w.hard_path;
     q.rays[ 0 ] = w.rays[ 0 ]; q.rays[ 1 ] = w.rays[ 1 ];
     q.stacks = w.stacks; q.stack_cap = h->tun.stack_cap; q.stack_use = h->tun.stack_use;
@@ -944,6 +1009,12 @@ static uint32_t walk_passes_of_level( const acn_scene_handle* h, int level )
     const uint64_t depth_left = h->dev.prm.trace_depth > 10ull * ( uint64_t )level ? h->dev.prm.trace_depth - 10ull * ( uint64_t )level : 1;
     uint32_t passes = h->tun.walk_passes;
     if( passes > depth_left + 1 ) passes = ( uint32_t )depth_left + 1;
+    /* The chunks of a call see the same mix of pixels (TileOrder), so the passes that had input in the last chunk, plus
+     * one, are the passes this chunk needs: the last launch of a level finishes whatever is left on the private stacks in
+     * any case, so a guess that is too low costs time, never rays.  (A frame without specular surfaces: 2 launches per
+     * level instead of 12.) */
+    const uint32_t seen = h->walk_passes_seen[ level ];
+    if( seen && seen + 1 < passes ) passes = seen + 1;
     return passes;
 }
 
@@ -956,10 +1027,10 @@ static uint32_t walk_passes_of_level( const acn_scene_handle* h, int level )
  * launches of waves that exit at once.  The host synchronises ONCE, at the end, to read the counter blocks: overflow
  * flags (the chunk is then redone smaller) and statistics. */
 static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t first_pixel, uint32_t base, uint32_t cnt, TileOrder order,
-                         hipStream_t stream, int* overflow, uint32_t* fullest )
+                         hipStream_t stream, int* overflow, uint32_t* fill )
 {
     *overflow = 0;
-    *fullest = 0;
+    for( int q = 0; q < WQ_N; q++ ) fill[ q ] = 0;
     const int levels = h->n_levels;
     const KernelFlags f = kernel_flags( h );
     const SceneArgs s = scene_args( h );
@@ -973,8 +1044,10 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
          * many generations as its hits have depth left */
         if( level > 0 ) ACN_LAUNCH( h, 0, stream, acn_launch_shade_hits( f.count, q, stream, s, h->d_accum, h->d_counters ) );
         const uint32_t passes = walk_passes_of_level( h, level );
+        LevelQ qw = q;
+        qw.grid = h->walk_grid;
         for( uint32_t pass = 0; pass < passes; pass++ )
-            ACN_LAUNCH( h, 0, stream, acn_launch_walk( f, pass, pass + 1 == passes, q, lds, stream, s, d_pos_xy, first_pixel, base,
+            ACN_LAUNCH( h, 0, stream, acn_launch_walk( f, pass, pass + 1 == passes, qw, lds, stream, s, d_pos_xy, first_pixel, base,
                                                        level == 0 && pass == 0 ? cnt : 0u, order, h->d_accum, h->d_counters ) );
         ACN_LAUNCH( h, 1, stream, acn_launch_shade64( f, q, stream, s, h->d_accum, h->d_counters ) );
         ACN_LAUNCH( h, 1, stream, acn_launch_shade16( f, q, stream, s, h->d_accum, h->d_counters ) );
@@ -995,6 +1068,19 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
         if( c[ QC_GEN + walk_passes_of_level( h, level ) ] ) flags |= ACN_FLAG_CHILD_OVERFLOW;   /* rays left over by the last pass */
     }
     h->flags_seen |= flags & ACN_FLAG_CLAMPED;
+    /* what the chunk put into each queue (high-water marks of reserved slots, dead slots included; of a chunk that
+     * overflowed: at least this much): the next chunk's size and the queue capacities are derived from it */
+    for( int level = 0; level < levels; level++ )
+    {
+        const uint32_t* c = h->h_counts + ( size_t )level * QC_N;
+        auto up = [ & ]( int q, uint32_t v ) { if( v > fill[ q ] ) fill[ q ] = v; };
+        up( WQ_TASKS, c[ QC_TASKS ] );
+        for( int k = 0; k < ACN_NCLASS; k++ ) up( WQ_TASKS, c[ QC_CLASS0 + k ] );
+        up( WQ_CHILDREN, c[ QC_CHILDREN ] );
+        up( WQ_HARD_SHADOW, c[ QC_HARD_SHADOW ] );
+        up( WQ_HARD_PATH, c[ QC_HARD_PATH ] );
+        for( int g = 0; g <= ACN_MAX_WALK_PASSES; g++ ) up( WQ_RAYS, c[ QC_GEN + g ] );
+    }
     if( flags & ACN_FLAG_STACK_OVERFLOW ) return fail( ACN_ERR_UNSUPPORTED, "device CSG / compound stack overflow (or a walk that did not end)" );
     if( flags & ( ACN_FLAG_TASK_OVERFLOW | ACN_FLAG_CHILD_OVERFLOW ) ) { *overflow = 1; return ACN_OK; }
     for( int level = 0; level < levels; level++ )
@@ -1008,13 +1094,22 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
         h->shade_hit_recs += c[ QS_CHILDREN ];
         if( c[ QC_TASKS ] > h->peak_tasks ) h->peak_tasks = c[ QC_TASKS ];
         if( c[ QC_CHILDREN ] > h->peak_children ) h->peak_children = c[ QC_CHILDREN ];
-        /* the fullest queue of the chunk: what the next chunk's size is derived from */
-        const int q_slots[] = { QC_TASKS, QC_CLASS0, QC_CLASS0 + 1, QC_CLASS0 + 2, QC_CLASS0 + 3, QC_CHILDREN, QC_HARD_PATH };
-        for( int k : q_slots ) if( c[ k ] > *fullest ) *fullest = c[ k ];
-        if( c[ QC_HARD_SHADOW ] / 2 > *fullest ) *fullest = c[ QC_HARD_SHADOW ] / 2;   /* that queue has twice the slots (LevelQ.hs_cap) */
-        for( int g = 0; g <= ACN_MAX_WALK_PASSES; g++ ) if( c[ QC_GEN + g ] > *fullest ) *fullest = c[ QC_GEN + g ];
         h->private_rays += c[ QS_PRIVATE_RAYS ];
         h->probe_rays += c[ QS_PROBES ];
+    }
+    if( cnt >= 4096 )   /* a chunk large enough to stand for the next one */
+    {
+        uint32_t seen[ ACN_MAX_PATH_LEVELS + 1 ];
+        for( int level = 0; level < levels; level++ )
+        {
+            const uint32_t* c = h->h_counts + ( size_t )level * QC_N;
+            const uint32_t launched = walk_passes_of_level( h, level );
+            uint32_t used = 1;   /* pass 0 of level 0 has the camera rays; a level without rays keeps one launch */
+            for( uint32_t g = 0; g < launched; g++ ) if( c[ QC_GEN + g ] ) used = g + 1;
+            /* the last launch ran in private mode: if it still had input the level may need more passes than were launched */
+            seen[ level ] = ( used == launched && launched > 1 ) ? used + 2 : used;
+        }
+        for( int level = 0; level < levels; level++ ) h->walk_passes_seen[ level ] = seen[ level ];
     }
     return ACN_OK;
 }
@@ -1053,15 +1148,15 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     HIP_TRY( hipEventRecord( h->ev0, stream ) );
     HIP_TRY( hipMemsetAsync( h->d_accum, 0, sizeof( unsigned long long ) * 3 * n, stream ) );
 
-    /* Positions per pipeline run.  How many records a position produces differs by orders of magnitude between scenes
-     * (wine_glass: 30 deferred shadow rays per pixel; a closed room at path_samples 1024: 260 000 second-level hits), so
-     * the size is learned: a cautious first chunk, then 70 % of what the fullest queue of the last chunk says fits; an
-     * overflow halves the chunk.  The estimate stays with the handle for its next call. */
+    /* Positions per pipeline run.  How many records a position leaves in each queue differs by orders of magnitude between
+     * scenes (wine_glass: 15 deferred shadow rays per pixel; a closed room at path_samples 1024: 260 000 second-level hits),
+     * so the rates are learned: a cautious first chunk on a small starter workspace, then chunks that fill the fullest
+     * queue to 70 %, and the queues themselves re-sized once the rates are known (ensure_workspace); an overflow halves
+     * the chunk.  Rates and workspace stay with the handle for its next call. */
     size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
-    const double cap = ( double )h->ws.cap;
     size_t chunk;
-    if( h->recs_per_pos > 0 ) chunk = ( size_t )( 0.7 * cap / h->recs_per_pos );
-    else chunk = ( size_t )( cap / ( ( double )( s + 2 ) * ( s > 16 ? ( double )s / 16.0 : 1.0 ) ) );
+    if( rates_known( h ) ) chunk = chunk_for_caps( h );
+    else chunk = ( size_t )( ( double )h->ws.cap[ WQ_TASKS ] / ( ( double )( s + 2 ) * ( s > 16 ? ( double )s / 16.0 : 1.0 ) ) );
     if( h->tun.chunk ) chunk = h->tun.chunk;
     if( chunk < 64 ) chunk = 64;
     /* the order of work: tiles of 256 positions in a multiplicative stride over the call (TileOrder) */
@@ -1083,33 +1178,50 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
         if( opts && opts->cancel && *opts->cancel ) return fail( ACN_ERR_CANCELLED, "cancelled" );
         uint32_t cnt = ( uint32_t )( ( n_slots - base < chunk ) ? n_slots - base : chunk );
         int overflow = 0;
-        uint32_t fullest = 0;
-        st = render_chunk( h, d_pos_xy, first, ( uint32_t )base, cnt, order, stream, &overflow, &fullest );
+        uint32_t fill[ WQ_N ];
+        /* the work counters of a chunk that has to be redone must not count twice */
+        if( h->count_work ) HIP_TRY( hipMemcpyAsync( h->d_counters_keep, h->d_counters, sizeof( unsigned long long ) * ACN_CNT_SLOTS, hipMemcpyDeviceToDevice, stream ) );
+        st = render_chunk( h, d_pos_xy, first, ( uint32_t )base, cnt, order, stream, &overflow, fill );
         if( st != ACN_OK ) return st;
         if( overflow )
         {
             if( cnt <= 1 ) return fail( ACN_ERR_DEVICE, "work queues overflow for a single position: raise ACN_WORKSPACE_MB" );
+            if( h->count_work ) HIP_TRY( hipMemcpyAsync( h->d_counters, h->d_counters_keep, sizeof( unsigned long long ) * ACN_CNT_SLOTS, hipMemcpyDeviceToDevice, stream ) );
             h->retries++;
+            /* the marks of an overflowed chunk are lower bounds of its demand */
+            for( int q = 0; q < WQ_N; q++ ) { const double r = ( double )fill[ q ] / ( double )cnt; if( r > h->rate[ q ] ) h->rate[ q ] = r; }
+            for( int level = 0; level <= ACN_MAX_PATH_LEVELS; level++ ) h->walk_passes_seen[ level ] = 0;   /* the full number of passes again */
             chunk = cnt / 2;
-            h->recs_per_pos = cap / ( double )chunk;
             hipLaunchKernelGGL( k_clear_slots, dim3( ( cnt + 255 ) / 256 ), dim3( 256 ), 0, stream, h->d_accum, ( uint32_t )base, cnt, order );
             HIP_TRY( hipGetLastError() );
             continue;
         }
         h->chunks++;
         base += cnt;
-        if( !h->tun.chunk && ( cnt >= 16384 || h->recs_per_pos == 0 ) )
+        if( h->tun.chunk ) continue;
+        /* Learn.  A chunk much larger than the one the rates came from replaces them (the dead slots at the ends of the
+         * waves' queue reservations do not scale with the chunk, so small chunks over-estimate); otherwise the rates
+         * follow upwards at once and forget slowly. */
+        const bool known = rates_known( h );
+        if( !known || cnt >= 4 * h->rate_cnt )
         {
-            /* (small chunks over-estimate: the dead slots at the ends of the waves' queue reservations do not scale) */
-            double per_pos = ( double )fullest / ( double )cnt;
-            if( per_pos < 0.9 * h->recs_per_pos ) per_pos = 0.9 * h->recs_per_pos;   /* forget slowly */
-            if( per_pos < 1e-3 ) per_pos = 1e-3;
-            h->recs_per_pos = per_pos;
-            double next = 0.7 * cap / per_pos;
-            if( next > 2.0e9 ) next = 2.0e9;
-            chunk = ( size_t )next;
-            if( chunk < 64 ) chunk = 64;
+            for( int q = 0; q < WQ_N; q++ ) h->rate[ q ] = f_max_host( ( double )fill[ q ] / ( double )cnt, 1e-3 );
+            h->rate_cnt = cnt;
         }
+        else if( cnt >= 16384 || cnt >= h->rate_cnt )
+        {
+            for( int q = 0; q < WQ_N; q++ ) h->rate[ q ] = f_max_host( f_max_host( ( double )fill[ q ] / ( double )cnt, 0.9 * h->rate[ q ] ), 1e-3 );
+            if( cnt > h->rate_cnt ) h->rate_cnt = cnt;
+        }
+        const size_t remaining = n_slots - base;
+        if( remaining && chunk_for_caps( h ) < remaining )
+        {
+            /* more than one further chunk with these queues: re-size them (a no-op when they already are what the budget
+             * allows).  Rates that come from a small chunk are trusted for a medium one only. */
+            const size_t target = h->rate_cnt < 32768 ? ( remaining < 65536 ? remaining : ( size_t )65536 ) : remaining;
+            if( ( st = ensure_workspace( h, target ) ) != ACN_OK ) return st;
+        }
+        chunk = chunk_for_caps( h );
     }
     if( ( st = stage_begin( h, 2, stream ) ) != ACN_OK ) return st;
     hipLaunchKernelGGL( k_finalize, dim3( ( unsigned )( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, stream,
@@ -1188,14 +1300,17 @@ static int make_lane( acn_scene_handle* parent, int lanes, acn_scene_handle** ou
     l->lds_bytes = parent->lds_bytes; l->lds_stack_bytes = parent->lds_stack_bytes;
     l->prune = parent->prune; l->leaf_lights = parent->leaf_lights;
     l->tun = parent->tun; l->cus = parent->cus; l->n_levels = parent->n_levels;
+    l->workspace_budget = parent->workspace_budget;
     l->grid = parent->tun.grid ? parent->tun.grid : parent->cus * 2u;
     l->shade_grid = parent->tun.shade_grid ? parent->tun.shade_grid : parent->cus * 2u;
+    l->walk_grid = parent->tun.walk_grid ? parent->tun.walk_grid : l->grid;
 #define HIP_TRY_L( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) { acn_scene_free( l ); return fail( ACN_ERR_DEVICE, hipGetErrorString( e_ ) ); } } while( 0 )
     HIP_TRY_L( hipStreamCreateWithFlags( &l->stream, hipStreamNonBlocking ) );
     HIP_TRY_L( hipEventCreate( &l->ev0 ) );
     HIP_TRY_L( hipEventCreate( &l->ev1 ) );
     HIP_TRY_L( hipMalloc( &l->d_counters, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
     HIP_TRY_L( hipMemset( l->d_counters, 0, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
+    HIP_TRY_L( hipMalloc( &l->d_counters_keep, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
     HIP_TRY_L( hipMalloc( &l->d_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
     HIP_TRY_L( hipMemset( l->d_counts, 0, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
     HIP_TRY_L( hipHostMalloc( &l->h_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
@@ -1290,9 +1405,25 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
         h->peak_tasks += l->peak_tasks; h->peak_children += l->peak_children;
     }
     h->used_lanes = true;
+    h->lanes_used = lanes;
     h->timed = true;
     return ACN_OK;
 }
+
+/* the caller's options as far as the caller's header knew them (acn_render_opts.struct_size), the rest zero */
+static acn_render_opts opts_of( const acn_render_opts* in )
+{
+    acn_render_opts o{};
+    if( in )
+    {
+        size_t n = in->struct_size ? in->struct_size : offsetof( acn_render_opts, shard_mode );
+        if( n > sizeof( o ) ) n = sizeof( o );
+        memcpy( &o, in, n );
+    }
+    o.struct_size = ( uint32_t )sizeof( o );
+    return o;
+}
+#define ACN_OPTS_VIEW const acn_render_opts opts_seen_ = opts_of( opts ); opts = &opts_seen_;
 
 /* one pipeline run on the handle itself, or the concurrent lanes */
 static int render_dispatch( acn_scene_handle* h, const double* d_pos_xy, size_t first, size_t n, double* d_out_rgb,
@@ -1307,6 +1438,7 @@ static int render_dispatch( acn_scene_handle* h, const double* d_pos_xy, size_t 
 extern "C" int acn_render_positions_dev( acn_scene_handle* h, const void* d_pos_xy, size_t n, void* d_out_rgb,
                                          const acn_render_opts* opts )
 {
+    ACN_OPTS_VIEW
     if( !h || ( n && ( !d_pos_xy || !d_out_rgb ) ) ) return fail( ACN_ERR_ARG, "null argument" );
     HIP_TRY( hipSetDevice( h->device ) );
     hipStream_t stream = ( opts && opts->stream ) ? ( hipStream_t )opts->stream : h->stream;
@@ -1319,6 +1451,7 @@ extern "C" int acn_render_positions_dev( acn_scene_handle* h, const void* d_pos_
 extern "C" int acn_render_main_pass_dev( acn_scene_handle* h, size_t first, size_t count, void* d_out_rgb,
                                          const acn_render_opts* opts )
 {
+    ACN_OPTS_VIEW
     if( !h || ( count && !d_out_rgb ) ) return fail( ACN_ERR_ARG, "null argument" );
     if( first + count > h->dev.prm.image_width * h->dev.prm.image_height ) return fail( ACN_ERR_ARG, "pixel range outside the image" );
     HIP_TRY( hipSetDevice( h->device ) );
@@ -1332,6 +1465,7 @@ extern "C" int acn_render_main_pass_dev( acn_scene_handle* h, size_t first, size
 extern "C" int acn_render_positions( acn_scene_handle* h, const double* pos_xy, size_t n, double* out_rgb,
                                      const acn_render_opts* opts )
 {
+    ACN_OPTS_VIEW
     if( !h || ( n && ( !pos_xy || !out_rgb ) ) ) return fail( ACN_ERR_ARG, "null argument" );
     if( n == 0 ) return ACN_OK;
     HIP_TRY( hipSetDevice( h->device ) );
@@ -1382,6 +1516,7 @@ __global__ void k_shard_unpack( const double* __restrict__ gathered, size_t n, u
 extern "C" int acn_render_main_pass_shard_dev( acn_scene_handle* h, size_t first, size_t count, uint32_t rank, uint32_t world,
                                                void* d_part, const acn_render_opts* opts )
 {
+    ACN_OPTS_VIEW
     if( !h || ( count && !d_part ) || world == 0 || rank >= world ) return fail( ACN_ERR_ARG, "bad argument" );
     if( first + count > h->dev.prm.image_width * h->dev.prm.image_height ) return fail( ACN_ERR_ARG, "pixel range outside the image" );
     HIP_TRY( hipSetDevice( h->device ) );
@@ -1410,6 +1545,7 @@ extern "C" int acn_render_main_pass_shard_dev( acn_scene_handle* h, size_t first
 extern "C" int acn_shard_unpack_dev( acn_scene_handle* h, const void* d_gathered, size_t count, uint32_t world, void* d_frame,
                                      const acn_render_opts* opts )
 {
+    ACN_OPTS_VIEW
     if( !h || ( count && ( !d_gathered || !d_frame ) ) || world == 0 ) return fail( ACN_ERR_ARG, "bad argument" );
     if( count == 0 ) return ACN_OK;
     HIP_TRY( hipSetDevice( h->device ) );
@@ -1424,6 +1560,7 @@ extern "C" int acn_shard_unpack_dev( acn_scene_handle* h, const void* d_gathered
 extern "C" int acn_resolve_dev( acn_scene_handle* h, const void* d_linear_rgb, size_t n, void* d_out_rgb, void* d_out_rgb8,
                                 const acn_render_opts* opts )
 {
+    ACN_OPTS_VIEW
     if( !h || ( n && !d_linear_rgb ) ) return fail( ACN_ERR_ARG, "null argument" );
     if( n == 0 ) return ACN_OK;
     HIP_TRY( hipSetDevice( h->device ) );
@@ -1448,16 +1585,16 @@ extern "C" int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms )
 
 extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
 {
-    if( !h || !out || n < 0 || n > 23 || !h->timed ) return fail( ACN_ERR_ARG, "no timed launch" );
+    if( !h || !out || n < 0 || n > 24 || !h->timed ) return fail( ACN_ERR_ARG, "no timed launch" );
     HIP_TRY( hipSetDevice( h->device ) );
     HIP_TRY( hipEventSynchronize( h->ev1 ) );
     double ms[ 4 ] = { 0, 0, 0, 0 };
-    size_t queue_cap = h->ws.cap;
+    size_t queue_cap = h->ws.cap[ WQ_HARD_SHADOW ], ws_bytes = h->ws.bytes;
     std::vector< const acn_scene_handle* > src{ h };
-    if( h->used_lanes ) { src.assign( h->lanes.begin(), h->lanes.end() ); queue_cap = 0; }   /* stage times: summed over the concurrent lanes */
+    if( h->used_lanes ) { src.assign( h->lanes.begin(), h->lanes.begin() + h->lanes_used ); queue_cap = 0; ws_bytes = 0; }   /* stage times: summed over the concurrent lanes of the call */
     for( const acn_scene_handle* l : src )
     {
-        if( h->used_lanes ) queue_cap += l->ws.cap;
+        if( h->used_lanes ) { queue_cap += l->ws.cap[ WQ_HARD_SHADOW ]; ws_bytes += l->ws.bytes; }
         for( size_t i = 0; i < l->events_used; i++ )
         {
             float t = 0;
@@ -1467,23 +1604,23 @@ extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
     }
     float total = 0;
     HIP_TRY( hipEventElapsedTime( &total, h->ev0, h->ev1 ) );
-    double v[ 23 ] = { ms[ 0 ], ms[ 1 ], ms[ 2 ], total, ( double )h->launches[ 0 ], ( double )h->launches[ 1 ], ( double )h->launches[ 2 ],
+    double v[ 24 ] = { ms[ 0 ], ms[ 1 ], ms[ 2 ], total, ( double )h->launches[ 0 ], ( double )h->launches[ 1 ], ( double )h->launches[ 2 ],
                        ( double )h->chunks, ( double )h->retries, ( double )h->levels, ( double )h->peak_tasks, ( double )h->peak_children,
                        ( double )queue_cap, ms[ 3 ], ( double )h->launches[ 3 ], ( double )h->hard_rays,
                        ( double )h->walk_rays, ( double )h->shade_hit_recs, ( double )h->host_syncs, ( double )h->walk_steps,
-                       ( double )h->flags_seen, ( double )h->private_rays, ( double )h->probe_rays };
-    for( int k = 0; k < n && k < 23; k++ ) out[ k ] = v[ k ];
+                       ( double )h->flags_seen, ( double )h->private_rays, ( double )h->probe_rays, ( double )ws_bytes };
+    for( int k = 0; k < n && k < 24; k++ ) out[ k ] = v[ k ];
     return ACN_OK;
 }
 
 extern "C" int acn_last_counters( acn_scene_handle* h, uint64_t* out, int n )
 {
-    if( !h || !out || n < 0 || n > 64 ) return fail( ACN_ERR_ARG, "bad argument" );
+    if( !h || !out || n < 0 || n > ACN_CNT_SLOTS ) return fail( ACN_ERR_ARG, "bad argument" );
     HIP_TRY( hipSetDevice( h->device ) );
     unsigned long long c[ ACN_CNT_SLOTS ], sum[ ACN_CNT_SLOTS ];
     for( int k = 0; k < ACN_CNT_SLOTS; k++ ) sum[ k ] = 0;
     std::vector< const acn_scene_handle* > src{ h };
-    if( h->used_lanes ) src.assign( h->lanes.begin(), h->lanes.end() );
+    if( h->used_lanes ) src.assign( h->lanes.begin(), h->lanes.begin() + h->lanes_used );
     for( const acn_scene_handle* l : src )
     {
         HIP_TRY( hipMemcpy( c, l->d_counters, sizeof( c ), hipMemcpyDeviceToHost ) );

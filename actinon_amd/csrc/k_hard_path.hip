@@ -7,7 +7,8 @@
 void acn_launch_hard_path( KernelFlags f, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
                            unsigned long long* accum, unsigned long long* counters )
 {
-    if( f.count )      { if( f.lds_nodes ) ACN_LHP_( true, true, false );  else ACN_LHP_( true, false, false ); }
+    if( f.count && f.prune ) { if( f.lds_nodes ) ACN_LHP_( true, true, true );  else ACN_LHP_( true, false, true ); }
+    else if( f.count ) { if( f.lds_nodes ) ACN_LHP_( true, true, false );  else ACN_LHP_( true, false, false ); }
     else if( f.prune ) { if( f.lds_nodes ) ACN_LHP_( false, true, true );  else ACN_LHP_( false, false, true ); }
     else               { if( f.lds_nodes ) ACN_LHP_( false, true, false ); else ACN_LHP_( false, false, false ); }
 }

@@ -64,6 +64,7 @@ static int run_on_handle( acn_scene_handle* h, acn_lum* lum_arr, size_t n, const
     for( size_t i = 0; i < n; i++ ) { pos[ i * 2 ] = lum_arr[ i ].pos_x; pos[ i * 2 + 1 ] = lum_arr[ i ].pos_y; }
     acn_render_opts opts;
     memset( &opts, 0, sizeof( opts ) );
+    opts.struct_size = ( uint32_t )sizeof( opts );
     opts.cancel = cancel;
     int st = acn_render_positions( h, pos, n, clr, &opts );
     if( st == ACN_OK )

@@ -233,6 +233,7 @@ class Handle:
 
     def _opts(self, linear, stream):
         o = abi.RenderOpts()
+        o.struct_size = C.sizeof(abi.RenderOpts)
         o.flags = ((abi.ACN_OPT_LINEAR_OUT if linear else 0) | (abi.ACN_OPT_COUNT_WORK if self.count_work else 0)
                    | (abi.ACN_OPT_STAGE_TIMING if self.stage_timing else 0))
         o.stream = stream
@@ -284,9 +285,10 @@ class Handle:
         """Per-stage device time (ms) and pipeline statistics of the last render call."""
         names = ["walk_ms", "shade_ms", "finalize_ms", "total_ms", "walk_launches", "shade_launches", "finalize_launches",
                  "chunks", "retries", "levels", "peak_tasks", "peak_children", "queue_cap", "hard_ms", "hard_launches",
-                 "hard_rays", "walk_rays", "path_hits", "host_syncs", "walk_steps", "flags", "private_rays", "probe_rays"]
-        buf = (C.c_double * 23)()
-        check(hip.acn_last_stage_ms(self.h, buf, 23), "acn_last_stage_ms")
+                 "hard_rays", "walk_rays", "path_hits", "host_syncs", "walk_steps", "flags", "private_rays", "probe_rays",
+                 "workspace_bytes"]
+        buf = (C.c_double * 24)()
+        check(hip.acn_last_stage_ms(self.h, buf, 24), "acn_last_stage_ms")
         return dict(zip(names, [float(v) for v in buf]))
 
     def last_counters(self):
@@ -306,10 +308,10 @@ class Handle:
 
     def last_phase_ticks(self):
         """{kernel: {phase: shader-clock ticks}} of a library built with -DACN_PHASE_TIMERS (all zero otherwise)"""
-        buf = (C.c_uint64 * 58)()
-        check(hip.acn_last_counters(self.h, buf, 58), "acn_last_counters")
+        buf = (C.c_uint64 * 74)()
+        check(hip.acn_last_counters(self.h, buf, 74), "acn_last_counters")
         out = {}
-        for k, kernel in enumerate(["walk", "hard_shadow", "hard_path"]):
+        for k, kernel in enumerate(["walk", "hard_shadow", "hard_path", "shade"]):
             out[kernel] = {p: int(buf[10 + 16 * k + i]) for i, p in enumerate(self.PHASES)}
         return out
 

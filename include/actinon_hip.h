@@ -169,7 +169,9 @@ typedef struct acn_flat_scene
 typedef struct acn_render_opts
 {
     uint32_t flags;
-    int32_t  reserved;
+    uint32_t struct_size;          /* sizeof( acn_render_opts ) as the CALLER was compiled; 0 = the first layout of this struct
+                                      (24 bytes: flags .. stream).  The library reads no member beyond it, so a host built
+                                      against an older header keeps working when members are appended (ACN_RENDER_OPTS_INIT) */
     const volatile int* cancel;    /* optional; polled between launches; the SIGINT flag of src/scene.c:893,978 */
     void*    stream;               /* optional hipStream_t; NULL = the handle's own stream */
     uint32_t shard_mode;           /* ACN_SHARD_* */
@@ -177,6 +179,7 @@ typedef struct acn_render_opts
     uint32_t shard_world;          /* 0 or 1: the call is not sharded */
     uint32_t reserved2;
 } acn_render_opts;
+#define ACN_RENDER_OPTS_INIT { 0u, ( uint32_t )sizeof( acn_render_opts ), 0, 0, ACN_SHARD_NONE, 0u, 0u, 0u }
 
 typedef struct acn_scene_handle acn_scene_handle;
 
@@ -249,19 +252,20 @@ int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms );
  * lanes (ACN_LANES, default 4 for large calls) the per-stage values are SUMS over the lanes and can exceed the total)
  * and pipeline statistics:
  * out[0] walk kernels ms, [1] shade kernels ms, [2] finalize ms, [3] total ms, [4..6] launches per stage, [7] chunks,
- * [8] overflow retries, [9] path levels run, [10] peak shading tasks, [11] peak child hits, [12] queue capacity,
+ * [8] overflow retries, [9] path levels run, [10] peak shading tasks, [11] peak child hits, [12] slots of the largest queue,
  * [13] hard-ray kernels ms, [14] their launches, [15] hard rays, [16] rays traced by the specular walk (camera rays
  * included), [17] path-sample hits shaded (levels >= 1), [18] host synchronisations inside the pipeline (one per chunk),
  * [19] 64-ray steps of the walk kernel's waves ([16] / ( 64 * [19] ) is its lane occupancy), [20] ACN_FLAG_* bits seen
  * (8: a pixel contribution exceeded the fixed-point clamp of 16384), [21] rays the walk finished on the waves' private
  * stacks instead of in generation passes, [22] specular rays whose radiance is zero on a hit (depth 0 or intensity below
- * trace_min_intensity, src/scene.c:430) and that were therefore answered by an any-hit probe instead of a walk. n <= 23. */
+ * trace_min_intensity, src/scene.c:430) and that were therefore answered by an any-hit probe instead of a walk, [23] bytes
+ * of device memory the call's work queues and ray stacks occupy (all lanes). n <= 24. */
 int acn_last_stage_ms( acn_scene_handle* h, double* out, int n );
 
 /* Work counters of the last render call (rays cast, node visits ...), see DESIGN.md: [0..7] events, [8] flop and
  * [9] transcendental calls by the cost table (ACN_OPT_COUNT_WORK).  [10 + 16 * kernel + phase] (kernel 0 walk, 1 hard
- * shadow, 2 hard path): shader-clock ticks the kernel's waves spent per phase, filled only by a diagnostic build of
- * the library (EXTRA_DEFS=-DACN_PHASE_TIMERS), zero otherwise. n <= 64. */
+ * shadow, 2 hard path, 3 shade): shader-clock ticks the kernel's waves spent per phase, filled only by a diagnostic build
+ * of the library (EXTRA_DEFS=-DACN_PHASE_TIMERS), zero otherwise. n <= 74. */
 int acn_last_counters( acn_scene_handle* h, uint64_t* out, int n );
 
 /* MC bounding-sphere estimate of src/objects.c:312-363 for node `node` of an uploaded scene (GPU). */

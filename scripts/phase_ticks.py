@@ -20,7 +20,11 @@ for _ in range(2):
 torch.cuda.synchronize()
 st = hd.last_stages()
 print({k: round(v, 2) for k, v in st.items() if k.endswith("_ms")})
+SHADE_NAMES = {"m_leaf": "cap sample", "m_pair": "light hit", "m_frame": "oren-nayar + intensity", "m_side": "occlusion test",
+               "shade": "appends + sums", "compound": "path: sample + oren-nayar", "tail": "path: transition hit", "fetch": "task fetch + set-up"}
 for kernel, ph in hd.last_phase_ticks().items():
+    if kernel == "shade":     # slots 0 .. 3 hold the round tallies printed below
+        ph = {SHADE_NAMES[p]: v for p, v in ph.items() if p in SHADE_NAMES}
     tot = sum(ph.values())  # the tally slots are outside the named phases
     if not tot:
         continue
@@ -28,7 +32,7 @@ for kernel, ph in hd.last_phase_ticks().items():
     for p, v in ph.items():
         if v:
             print("   %-10s %5.1f %%" % (p, 100.0 * v / tot))
-buf = hd.last_counters_raw(64)
+buf = hd.last_counters_raw(74)
 for k, kernel in enumerate(["walk", "hard_shadow", "hard_path"]):
     t = [buf[10 + 16 * k + i] for i in (12, 13, 14, 15)]
     if t[1]:

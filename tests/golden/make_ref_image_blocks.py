@@ -1,6 +1,6 @@
 """Generates tests/golden/ref_image_blocks.json from the reference's own shipped renders.
 
-Run in the build container only (reads /root/reference/image/*.png; that tree does not exist on the GPU box):
+Run in the build container only (reads /root/reference/image/*.png|jpg; that tree does not exist on the GPU box):
     python tests/golden/make_ref_image_blocks.py
 
 The reference has no tests or golden vectors; its rendered example images are the only outputs of
@@ -21,7 +21,10 @@ BLOCK = 16
 IMAGES = {"primitives": "primitives.acn.png", "wine_glass": "wine_glass.acn.png", "diamond": "diamond.acn.png",
           "many_spheres": "many_spheres.acn.png", "pyramid": "pyramid.acn.png", "ruby_heart": "ruby_heart.acn.png",
           "caustic_of_caustic": "caustic_of_caustic.acn.png", "paraffin_lamp": "paraffin_lamp.acn.png",
-          "paraffin_lamp_on_ledge": "paraffin_lamp_on_ledge.acn.png", "hanging_lamp": "hanging_lamp_acn.png"}
+          "paraffin_lamp_on_ledge": "paraffin_lamp_on_ledge.acn.png", "hanging_lamp": "hanging_lamp_acn.png",
+          # frame 49 of src_acn/diamond_video.acn (400x300, the gem of diamond.acn through a second script) and the README's
+          # title picture: src_acn/hanging_lamps_in_row rendered at 3200x1800 and published scaled to 640x360 as JPEG
+          "diamond_video_049": "diamond_video.acn.image_000049.png", "hanging_lamps_in_row": "hanging_lamp02.acn.640_360.jpg"}
 
 
 def block_means(img, b):
@@ -32,7 +35,7 @@ def block_means(img, b):
 
 
 def main():
-    out = {"block": BLOCK, "unit": "8-bit value (0..255)", "source": "johsteffens/actinon image/*.png (CC-BY-SA 4.0)",
+    out = {"block": BLOCK, "unit": "8-bit value (0..255)", "source": "johsteffens/actinon image/*.png|jpg (CC-BY-SA 4.0)",
            "images": {}}
     for name, fn in IMAGES.items():
         img = np.asarray(Image.open(os.path.join(REF, fn)).convert("RGB"))

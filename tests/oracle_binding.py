@@ -12,9 +12,9 @@ COUNTER_NAMES = ["lum", "trans_ray", "shadow_ray", "obj_hit", "env_test", "plane
 
 
 class Oracle:
-    def __init__(self, libm=False):
+    def __init__(self, libm=False, path=None):
         name = "libacn_oracle_libm.so" if libm else "libacn_oracle.so"
-        path = os.path.join(ROOT, "oracle", name)
+        path = path or os.path.join(ROOT, "oracle", name)
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: run `make oracle`")
         self.lib = C.CDLL(path)

@@ -238,3 +238,39 @@ def test_bench_two_ranks_on_one_gpu_match_one_rank(tmp_path):
                         "--no-cpu-baseline", "--save-image", str(one)], env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert two.read_bytes() == one.read_bytes()
+
+
+def test_bench_two_ranks_sample_split_on_one_gpu(tmp_path):
+    """bench.py --split samples end to end: two ranks on the one GPU of the box (gloo between them), each renders EVERY pixel
+    but only its half of the outermost sample loops (ACN_SHARD_SAMPLES), the linear frames are sum-reduced, rank 0 resolves
+    after the reduce.  The partial sums are rounded to 2^-40 per rank instead of once, so the linear frame differs from a
+    one-rank run by <= 1e-10 (test_sample_shards_sum_to_the_unsharded_render); in the 8-bit image that can move a value
+    sitting on a quantisation boundary by one step, nothing more."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, ACN_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = tmp_path / "two.pnm"
+    one = tmp_path / "one.pnm"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--workload", "smoke", "--split", "samples", "--no-cpu-baseline", "--save-image", str(two)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["config"]["split"] == "samples" and "all_reduce" in line["config"]["exchange"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--workload", "smoke",
+                        "--no-cpu-baseline", "--save-image", str(one)], env=dict(os.environ), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = np.frombuffer(two.read_bytes(), dtype=np.uint8).astype(np.int16)
+    b = np.frombuffer(one.read_bytes(), dtype=np.uint8).astype(np.int16)
+    assert a.shape == b.shape
+    d = np.abs(a - b)
+    assert d.max() <= 1 and ( d != 0 ).mean() < 1e-3, ( d.max(), ( d != 0 ).mean() )
