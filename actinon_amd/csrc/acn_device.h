@@ -502,6 +502,31 @@ DEV V3 fresnel_refraction( V3 dir_i, V3 exit_nor, double trix )
 }
 
 /* ---- node access ---- */
+/* A node visit whose index is the same in every lane reads the node through the scalar cache.  Reading field by field,
+ * behind the branches that need them (type -> envelope -> position -> axes), makes every visit a chain of three or four
+ * DEPENDENT scalar loads of ~150-200 cycles each, which is what the lock-step machines wait for most of their time
+ * (profiles/r02/pmc_sq_final.txt: 0.6 of k_walk's wave cycles in s_waitcnt, 6e8 scalar loads per frame).  NodeView copies
+ * the whole 192-byte record into SGPRs at once -- three s_load_dwordx16 issued back to back, one wait -- and hands out
+ * a pointer to the copy; node arrays in other address spaces (LDS: per-lane indices) are passed through. */
+template< class NP > struct NodeView { NP p; DEV NodeView( NP q ) : p( q ) {} DEV NP ptr() const { return p; } };
+#ifdef ACN_PRELOAD_NODES
+template<> struct NodeView< const GNode ACN_CONST* >
+{
+    GNode v;
+    DEV NodeView( const GNode ACN_CONST* q )
+    {
+        v.type = q->type; v.flags = q->flags; v.child0 = q->child0; v.child1 = q->child1;
+        for( int k = 0; k < 4; k++ ) v.prm[ k ] = q->prm[ k ];
+        for( int k = 0; k < 3; k++ ) { v.pos[ k ] = q->pos[ k ]; v.env_pos[ k ] = q->env_pos[ k ]; }
+        v.env_radius = q->env_radius;
+        for( int k = 0; k < 9; k++ ) v.rax[ k ] = q->rax[ k ];
+        v.surface_roughness = q->surface_roughness; v.sdf_kind = q->sdf_kind; v.cycles = q->cycles;
+    }
+    DEV const GNode* ptr() const { return &v; }
+};
+#endif
+#define ACN_NODE( name, expr ) const auto name##_view_ = NodeView< decltype( expr ) >( expr ); const auto name = name##_view_.ptr();
+
 template< class NP > DEV bool node_has_env( NP n ) { return ( n->flags & ACN_NODE_HAS_ENVELOPE ) != 0; }
 template< class NP > DEV M3 node_rax( NP n )
 {
@@ -723,12 +748,12 @@ template< int L, bool SPLIT = false, class SR, class NP, class CT > DEV double p
 
 template< int L, class SR, class CT > DEV int operand_side( SR sc, int c, V3 pos, CT* cnt )
 {
-    auto cn = &sc.nodes[ c ];
+    ACN_NODE( cn, &sc.nodes[ c ] )
     cnt->inc( CNT_SIDE );
     if( node_has_env( cn ) && env_side( cn, pos ) == 1 ) return 1;
     if constexpr( L > 1 ) { if( cn->flags & ACN_GFLAG_LEAF_PAIR ) return pair_side< L - 1 >( sc, cn, pos, cnt ); }
     if( cn->type != ACN_NEG ) return simple_leaf_side( cn, pos );
-    auto g = &sc.nodes[ cn->child0 ];
+    ACN_NODE( g, &sc.nodes[ cn->child0 ] )
     cnt->inc( CNT_SIDE );
     int r = ( node_has_env( g ) && env_side( g, pos ) == 1 ) ? 1 : simple_leaf_side( g, pos );
     return -r;
@@ -748,7 +773,7 @@ template< class NP, class CT > DEV double simple_leaf_hit_( NP g, V3 rp, V3 rd, 
 
 template< int L, bool SPLIT = false, class SR, class CT > DEV double operand_hit( SR sc, int c, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
 {
-    auto cn = &sc.nodes[ c ];
+    ACN_NODE( cn, &sc.nodes[ c ] )
     cnt->inc( CNT_OBJ_HIT );
     if( node_has_env( cn ) && !env_ray_hits( cn, rp, rd ) ) return F3_INF;
     if constexpr( L > 1 )
@@ -761,7 +786,7 @@ template< int L, bool SPLIT = false, class SR, class CT > DEV double operand_hit
         }
     }
     if( cn->type != ACN_NEG ) return simple_leaf_hit( cn, rp, rd, want_nor, nor );
-    auto g = &sc.nodes[ cn->child0 ];
+    ACN_NODE( g, &sc.nodes[ cn->child0 ] )
     cnt->inc( CNT_OBJ_HIT );
     double a = ( node_has_env( g ) && !env_ray_hits( g, rp, rd ) ) ? F3_INF : simple_leaf_hit( g, rp, rd, want_nor, nor );
     if( a < F3_INF && want_nor )
@@ -1468,7 +1493,7 @@ DEV bool prune_exec( NP nodes, ElemP elems, int pc, V3 rp, V3 rd, double limit )
 template< bool NOR, class SC, class CT >
 DEV double element_hit( const SC& sc, int e, V3 rp, V3 rd, V3* nor, int* hit_obj, double limit, CT* cnt )
 {
-    auto n = &sc.nodes[ e ];
+    ACN_NODE( n, &sc.nodes[ e ] )
     int type = n->type;
     if( type == ACN_COMPOUND )
     {
@@ -1634,7 +1659,7 @@ DEV int root_occluded_fast( const SC& sc, int cmp, V3 rp, V3 rd, double limit, C
     for( int i = 0; i < count; i++ )
     {
         int element = __builtin_amdgcn_readfirstlane( sc.elems[ first + i ] );
-        auto n = &sc.nodes[ element ];
+        ACN_NODE( n, &sc.nodes[ element ] )
         int type = n->type;
         if( is_fast_type( type ) )
         {
@@ -1675,7 +1700,7 @@ DEV double root_trans_hit_fast( const SC& sc, int cmp, V3 rp, V3 rd, Trans* tran
     for( int i = 0; i < count; i++ )
     {
         int element = __builtin_amdgcn_readfirstlane( sc.elems[ first + i ] );
-        auto n = &sc.nodes[ element ];
+        ACN_NODE( n, &sc.nodes[ element ] )
         int type = n->type;
         if( !is_fast_type( type ) && !( n->flags & ( ACN_GFLAG_LEAF_PAIR | ( SC::prune ? ACN_GFLAG_SIMPLE_COMPOUND : 0u ) ) ) )
         {

@@ -72,7 +72,7 @@ struct LaneWorker
  * host that changes its environment, and would let a value change between the concurrent lanes of one call) */
 struct Tunables
 {
-    size_t   workspace_mb = 0;         /* ACN_WORKSPACE_MB: upper bound of the queue workspace of one handle (all its lanes); 0: 8 GiB or a
+    size_t   workspace_mb = 0;         /* ACN_WORKSPACE_MB: upper bound of the queue workspace of one handle (all its lanes); 0: 24 GiB or a
                                           quarter of the device memory that is free at upload, whichever is less */
     size_t   chunk = 0;                /* ACN_CHUNK: sample positions per pipeline run, 0 = derived from the queue capacity */
     int      lanes = 4;                /* ACN_LANES: concurrent pipeline runs of a large call */
@@ -473,10 +473,13 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     h->max_csg_depth = max_csg;
     h->tun.read();
     {
-        /* workspace budget of the handle: ACN_WORKSPACE_MB, or 8 GiB / a quarter of the free device memory */
+        /* Workspace budget of the handle: ACN_WORKSPACE_MB, or 24 GiB / a quarter of the free device memory.  The queues
+         * are sized from measured demand (ensure_workspace) and take what ONE chunk per lane needs, if the budget allows:
+         * every further chunk of a lane is another chain of ~45 dependent launches (1080p wine_glass, 4 lanes: 19 GiB and
+         * 71 ms with one chunk per lane; 8 GiB: 9 chunks, 91 ms; 4 GiB: 18 chunks, 125 ms) */
         size_t free_b = 0, total_b = 0;
         if( hipMemGetInfo( &free_b, &total_b ) != hipSuccess ) free_b = ( size_t )32 << 30;
-        h->workspace_budget = h->tun.workspace_mb ? h->tun.workspace_mb * 1024 * 1024 : ( ( size_t )8 << 30 );
+        h->workspace_budget = h->tun.workspace_mb ? h->tun.workspace_mb * 1024 * 1024 : ( ( size_t )24 << 30 );
         if( !h->tun.workspace_mb && h->workspace_budget > free_b / 4 ) h->workspace_budget = free_b / 4;
     }
     {
@@ -1156,7 +1159,12 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
     size_t chunk;
     if( rates_known( h ) ) chunk = chunk_for_caps( h );
-    else chunk = ( size_t )( ( double )h->ws.cap[ WQ_TASKS ] / ( ( double )( s + 2 ) * ( s > 16 ? ( double )s / 16.0 : 1.0 ) ) );
+    else
+    {
+        /* the starter queues are small: a first chunk of at most 8192 positions, fewer by the old quadratic guess */
+        chunk = ( size_t )( ( double )h->ws.cap[ WQ_TASKS ] / ( ( double )( s + 2 ) * ( s > 16 ? ( double )s / 16.0 : 1.0 ) ) );
+        if( chunk > 8192 ) chunk = 8192;
+    }
     if( h->tun.chunk ) chunk = h->tun.chunk;
     if( chunk < 64 ) chunk = 64;
     /* the order of work: tiles of 256 positions in a multiplicative stride over the call (TileOrder) */
