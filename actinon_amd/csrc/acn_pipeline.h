@@ -904,12 +904,16 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
             V3 fov_d; double cos_rs;
             if( sub == 0 ) cnt.cost( ACN_F_FOV + ACN_F_FRAME );   /* per task and light: booked by one lane of the group */
             obj_fov_dev( light_src, pos, &fov_d, &cos_rs );
-            M3 src_con = m_transposed( m_con_z( fov_d ) );
+            const M3 src_frame = m_con_z( fov_d );
+            const V3 src_con_z = src_frame.z;   /* the axis the cap samples are drawn around */
+            M3 src_con = m_transposed( src_frame );
             double cyl_hgt = 1 - cos_rs;
             uint64_t direct_samples = ( uint64_t )( sc.prm.direct_samples * diffuse_intensity );
             direct_samples = ( direct_samples == 0 ) ? 1 : direct_samples;
             V3 light_pos = ld3( light_src->pos );
             double radiance = light_mat->radiance;
+            /* root elements no shadow ray of this loop can reach (all of them lie in the light's sampling cone) */
+            const uint64_t skip = root_cone_cull( scp, sc.matter_root, pos, src_con_z, 1.0 - cyl_hgt );
             const V3 light_color = obj_color_dev( sc, light_idx, light_pos );   /* scene.c:552 */
 
             double s = 0;
@@ -946,7 +950,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 double local_intensity = ( diff_sqr > 0 ) ? ( radiance / diff_sqr ) : F3_MAG;
                 double c = local_intensity * weight * diffuse_intensity;
                 ACN_LAP( PH_M_FRAME );
-                int occ = root_occluded_fast( scp, sc.matter_root, pos, out_d, a, &cnt );
+                int occ = root_occluded_fast( scp, sc.matter_root, pos, out_d, a, skip, &cnt );
                 ACN_LAP( PH_M_SIDE );
                 if( occ == 0 ) { s += c; cnt.cost( ACN_F_DIRECT_TAIL ); }
                 /* hard shadow rays: appended to the queue of k_hard_shadow, which adds c itself if unoccluded */

@@ -72,7 +72,7 @@ struct LaneWorker
  * host that changes its environment, and would let a value change between the concurrent lanes of one call) */
 struct Tunables
 {
-    size_t   workspace_mb = 0;         /* ACN_WORKSPACE_MB: upper bound of the queue workspace of one handle (all its lanes); 0: 24 GiB or a
+    size_t   workspace_mb = 0;         /* ACN_WORKSPACE_MB: upper bound of the queue workspace of one handle (all its lanes); 0: 64 GiB or a
                                           quarter of the device memory that is free at upload, whichever is less */
     size_t   chunk = 0;                /* ACN_CHUNK: sample positions per pipeline run, 0 = derived from the queue capacity */
     int      lanes = 4;                /* ACN_LANES: concurrent pipeline runs of a large call */
@@ -158,6 +158,7 @@ struct acn_scene_handle
     unsigned grid = 1024, shade_grid = 1024;   /* workgroups of the persistent kernels / of k_shade */
     unsigned walk_grid = 1024;                 /* ... of k_walk */
     int n_levels = 1;                          /* path levels of the scene's trace_depth */
+    size_t n_lights = 1;                       /* elements of the light root */
     /* workspace of the wavefront pipeline */
     Workspace ws;
     uint32_t* d_counts = nullptr;              /* ACN_MAX_PATH_LEVELS + 1 counter blocks of QC_N words */
@@ -473,13 +474,15 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     h->max_csg_depth = max_csg;
     h->tun.read();
     {
-        /* Workspace budget of the handle: ACN_WORKSPACE_MB, or 24 GiB / a quarter of the free device memory.  The queues
-         * are sized from measured demand (ensure_workspace) and take what ONE chunk per lane needs, if the budget allows:
-         * every further chunk of a lane is another chain of ~45 dependent launches (1080p wine_glass, 4 lanes: 19 GiB and
-         * 71 ms with one chunk per lane; 8 GiB: 9 chunks, 91 ms; 4 GiB: 18 chunks, 125 ms) */
+        /* Workspace BOUND of the handle: ACN_WORKSPACE_MB, or 64 GiB / a quarter of the free device memory (288 GB per
+         * MI355X).  It is a bound, not an allocation: the queues are sized from measured demand (ensure_workspace) and take
+         * what ONE chunk per lane needs, if the bound allows -- every further chunk of a lane is another chain of ~45
+         * dependent launches (1080p wine_glass, 4 lanes: 20 GB and 71 ms with one chunk per lane; bound 8 GiB: 9 chunks, 91 ms;
+         * 4 GiB: 18 chunks, 125 ms).  Scenes whose demand per position is huge (path_samples 256 .. 1024: thousands of
+         * second-level hits per pixel) use the whole bound: many_spheres p256 at 24 GiB 532 chunks, 39 s; at 64 GiB ... */
         size_t free_b = 0, total_b = 0;
         if( hipMemGetInfo( &free_b, &total_b ) != hipSuccess ) free_b = ( size_t )32 << 30;
-        h->workspace_budget = h->tun.workspace_mb ? h->tun.workspace_mb * 1024 * 1024 : ( ( size_t )24 << 30 );
+        h->workspace_budget = h->tun.workspace_mb ? h->tun.workspace_mb * 1024 * 1024 : ( ( size_t )64 << 30 );
         if( !h->tun.workspace_mb && h->workspace_budget > free_b / 4 ) h->workspace_budget = free_b / 4;
     }
     {
@@ -773,6 +776,7 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     h->dev.prm = scene->params;
     {
         const acn_node& lr = scene->nodes[ scene->light_root ];
+        h->n_lights = lr.child1 > 0 ? ( size_t )lr.child1 : 1;
         for( int k = 0; k < lr.child1; k++ )
         {
             int t = scene->nodes[ scene->elems[ lr.child0 + k ] ].type;
@@ -891,9 +895,10 @@ static int ensure_workspace( acn_scene_handle* h, size_t n )
     size_t want[ WQ_N ];
     if( !rates_known( h ) )
     {
-        /* starter set: what a first chunk of a few thousand positions needs at the old quadratic guess, at most 2^20 records */
+        /* starter set: 2^20 records per queue (the deferred-shadow queue twice that), less for a call of a few positions */
         const size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
-        size_t recs = ( n < 8192 ? n : 8192 ) * ( s + 2 ) * ( s > 16 ? s / 16 : 1 ) + 65536;
+        const size_t per_pos = ( s + 2 ) * ( s > 16 ? s / 16 : 1 ) + ( size_t )h->dev.prm.direct_samples * h->n_lights;
+        size_t recs = n * per_pos + 65536;
         if( recs > ACN_STARTER_RECORDS ) recs = ACN_STARTER_RECORDS;
         size_t per_rec = wq_bytes[ WQ_HARD_SHADOW ];
         for( int q = 0; q < WQ_N; q++ ) per_rec += wq_bytes[ q ];
@@ -1161,8 +1166,11 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     if( rates_known( h ) ) chunk = chunk_for_caps( h );
     else
     {
-        /* the starter queues are small: a first chunk of at most 8192 positions, fewer by the old quadratic guess */
-        chunk = ( size_t )( ( double )h->ws.cap[ WQ_TASKS ] / ( ( double )( s + 2 ) * ( s > 16 ? ( double )s / 16.0 : 1.0 ) ) );
+        /* the starter queues are small: a first chunk of at most 8192 positions, fewer by a cautious guess -- path-sample hits
+         * quadratic in path_samples (two nested levels), every direct-light sample of every light a deferred shadow ray */
+        chunk = ( size_t )( ( double )h->ws.cap[ WQ_CHILDREN ] / ( ( double )( s + 2 ) * ( s > 16 ? ( double )s / 16.0 : 1.0 ) ) );
+        const size_t by_shadow = ( size_t )( 0.5 * ( double )h->ws.cap[ WQ_HARD_SHADOW ] / ( double )( h->dev.prm.direct_samples * h->n_lights + s + 4 ) );
+        if( chunk > by_shadow ) chunk = by_shadow;
         if( chunk > 8192 ) chunk = 8192;
     }
     if( h->tun.chunk ) chunk = h->tun.chunk;
@@ -1216,8 +1224,10 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
             for( int q = 0; q < WQ_N; q++ ) h->rate[ q ] = f_max_host( ( double )fill[ q ] / ( double )cnt, 1e-3 );
             h->rate_cnt = cnt;
         }
-        else if( cnt >= 16384 || cnt >= h->rate_cnt )
+        else
         {
+            /* (also after small chunks: where chunks are small the demand per position is large and the dead slots do not
+             * matter; rates that only went up left many_spheres p256 with 532 chunks of 3 900 positions after one spike) */
             for( int q = 0; q < WQ_N; q++ ) h->rate[ q ] = f_max_host( f_max_host( ( double )fill[ q ] / ( double )cnt, 0.9 * h->rate[ q ] ), 1e-3 );
             if( cnt > h->rate_cnt ) h->rate_cnt = cnt;
         }
@@ -1308,7 +1318,7 @@ static int make_lane( acn_scene_handle* parent, int lanes, acn_scene_handle** ou
     l->lds_bytes = parent->lds_bytes; l->lds_stack_bytes = parent->lds_stack_bytes;
     l->prune = parent->prune; l->leaf_lights = parent->leaf_lights;
     l->tun = parent->tun; l->cus = parent->cus; l->n_levels = parent->n_levels;
-    l->workspace_budget = parent->workspace_budget;
+    l->workspace_budget = parent->workspace_budget; l->n_lights = parent->n_lights;
     l->grid = parent->tun.grid ? parent->tun.grid : parent->cus * 2u;
     l->shade_grid = parent->tun.shade_grid ? parent->tun.shade_grid : parent->cus * 2u;
     l->walk_grid = parent->tun.walk_grid ? parent->tun.walk_grid : l->grid;
