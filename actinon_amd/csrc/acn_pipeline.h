@@ -152,6 +152,7 @@ struct HardPath
 };
 
 #define ACN_INVALID 0xFFFFFFFFu
+#define ACN_INVALID_SLOT 0xFFFFFFFFu
 #define ACN_NCLASS 4
 /* One counter block per path level (uint32 each), all blocks of a chunk zeroed by one memset before its first launch.
  * Queue counters are high-water marks of reserved slots (dead slots included); QS_* are exact statistics.
@@ -189,16 +190,36 @@ DEV int size_class( uint64_t n, uint32_t class0_min )
  * wave and queue, and is touched by one lane per append -- which makes appends legal under divergent control flow
  * (the sample loops of k_shade): the lanes that reach an append together form its ballot. */
 #define ACN_QCHUNK 64
-struct ChunkState { uint32_t cur, end; };
+/* spare: a second reservation taken ahead of need (chunk_prefetch), ACN_INVALID if none */
+struct ChunkState { uint32_t cur, end, spare, pad; };
 typedef ChunkState ACN_LDS* ChunkP;
 #define ACN_NCHUNKS 8     /* reservation states per wave */
 /* LDS block of the reservation states of a 256-lane workgroup; 256 B keeps the dynamic LDS behind it 16-byte aligned */
-#define ACN_CHUNK_STATES __shared__ ChunkState acn_chunk_states[ 4 * ACN_NCHUNKS ];
+#define ACN_CHUNK_STATES __shared__ __attribute__( ( aligned( 16 ) ) ) ChunkState acn_chunk_states[ 4 * ACN_NCHUNKS ];
 #define ACN_CHUNKS_OF_WAVE ( ( ChunkP )acn_chunk_states + ( threadIdx.x >> 6 ) * ACN_NCHUNKS )
 
 DEV void chunks_init( ChunkP cs )
 {
-    if( ( threadIdx.x & 63 ) < ACN_NCHUNKS ) { cs[ threadIdx.x & 63 ].cur = 0; cs[ threadIdx.x & 63 ].end = 0; }
+    if( ( threadIdx.x & 63 ) < ACN_NCHUNKS ) { cs[ threadIdx.x & 63 ].cur = 0; cs[ threadIdx.x & 63 ].end = 0; cs[ threadIdx.x & 63 ].spare = ACN_INVALID_SLOT; }
+}
+
+/* Reservations ahead of need.  A k_walk wave appends up to 64 records per step to each of its queues, so nearly every
+ * step runs a reservation dry and pays the round trip of a returning atomic (1-2 us) per queue in the middle of its
+ * shading.  At the start of a step (all lanes active, nothing else in flight) lane q looks at queue q of the wave: if its
+ * reservation exists and would not survive one more full step, the lane starts the atomic for the next one; the result
+ * is parked in LDS (ChunkState.spare) after the step's traversal, when it has long arrived, and chunk_alloc takes it
+ * from there.  One VGPR for all queues; a queue the wave never appended to is never reserved ahead. */
+struct ChunkPrefetch { uint32_t base; bool issued; };
+DEV void chunk_prefetch_issue( ChunkP cs, uint32_t* counter, bool enabled, ChunkPrefetch& pf )   /* lane q: cs = state of queue q */
+{
+    pf.base = 0;
+    const uint32_t cur = cs->cur, end = cs->end, spare = cs->spare;
+    pf.issued = enabled && end != 0u && end - cur < 64u && spare == ACN_INVALID_SLOT;
+    if( pf.issued ) pf.base = atomicAdd( counter, ( uint32_t )ACN_QCHUNK );
+}
+DEV void chunk_prefetch_park( ChunkP cs, const ChunkPrefetch& pf )
+{
+    if( pf.issued ) cs->spare = pf.base;
 }
 
 /* every lane with `want` gets a distinct slot of the queue counted by *counter.  A request that does not fit the rest
@@ -217,7 +238,9 @@ DEV uint32_t chunk_alloc( ChunkP cs, uint32_t* counter, bool want )
         base = cur; room = end - cur;
         if( m > room )
         {
-            base2 = atomicAdd( counter, ( uint32_t )ACN_QCHUNK );
+            const uint32_t spare = cs->spare;
+            if( spare != ACN_INVALID_SLOT ) { base2 = spare; cs->spare = ACN_INVALID_SLOT; }
+            else base2 = atomicAdd( counter, ( uint32_t )ACN_QCHUNK );
             cs->end = base2 + ACN_QCHUNK;
             cs->cur = base2 + ( m - room );
         }
@@ -234,8 +257,9 @@ DEV uint32_t chunk_alloc( ChunkP cs, uint32_t* counter, bool want )
 template< class KILL >
 DEV void chunk_close( ChunkP cs, uint32_t cap, KILL kill )
 {
-    uint32_t cur = cs->cur, end = cs->end;
+    uint32_t cur = cs->cur, end = cs->end, spare = cs->spare;
     for( uint32_t k = cur + ( threadIdx.x & 63 ); k < end; k += 64 ) if( k < cap ) kill( k );
+    if( spare != ACN_INVALID_SLOT ) for( uint32_t k = spare + ( threadIdx.x & 63 ); k < spare + ACN_QCHUNK; k += 64 ) if( k < cap ) kill( k );
 }
 
 /* one atomic per wave: every lane with `want` gets a distinct slot (unreserved form, used where appends are rare) */
@@ -700,6 +724,14 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
         uint32_t n_fresh = 0, fb = 0;
         if( n_pop < 64u ) n_fresh = range_take( fr, cursor, fetch_batch, n_in, 64u - n_pop, &fb );
         if( n_pop + n_fresh == 0 ) { finished = true; break; }
+        /* reservations this step may run dry: their atomics travel while the step's rays are traced (lane q: queue q of the
+         * wave -- 0 tasks, 1 .. 4 the class lists, 5 the next generation's rays, 6 probes) */
+        ChunkPrefetch pf;
+        {
+            const int q = lane < 7 ? lane : 0;
+            uint32_t* ctr = q == 0 ? &tq.counts[ QC_TASKS ] : q <= ACN_NCLASS ? &tq.counts[ QC_CLASS0 + q - 1 ] : q == 5 ? sink.out.counter : &tq.counts[ QC_HARD_SHADOW ];
+            chunk_prefetch_issue( cs + q, ctr, lane < 7 && !( q == 5 && sink.priv ), pf );
+        }
         sink.top -= n_pop;
         const RayTask* src = nullptr;
         bool live = false;
@@ -741,6 +773,7 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
             if constexpr( LDS ) offs = scene_trans_hit_dev( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), rp, rd, &trans, &cnt );
             else                offs = scene_trans_hit_dev( scene_view< PRUNE >( sc, sc.nodes ), rp, rd, &trans, &cnt );
         }
+        chunk_prefetch_park( cs + ( lane < 7 ? lane : 0 ), pf );
         /* what the ray carries is read only now, so that it does not occupy registers across the traversal */
         asm volatile( "" ::: "memory" );
         V3 T = mk( 1, 1, 1 );

@@ -87,6 +87,8 @@ struct Tunables
     uint32_t fetch_shade = 16;         /* ACN_FETCH_SHADE: steps ( of 64 / lanes-per-task tasks ) a k_shade wave reserves per cursor atomic */
     uint32_t fetch_hard = 256;         /* ACN_FETCH_HARD: records a wave of the hard-ray kernels / k_shade_hits reserves per atomic */
     uint32_t stack_use = 0;            /* ACN_TEST_STACK_USE: slots of a private stack every walk pass but the last uses (tests of the overflow path) */
+    bool     ws_uniform = false;       /* ACN_WS_UNIFORM=1: every queue gets the same share of the whole bound at once (round 2's layout; diagnostic) */
+    bool     learn_passes = true;      /* ACN_LEARN_PASSES=0: every level gets ACN_WALK_PASSES launches of k_walk, needed or not */
     bool     count_work = false;       /* ACN_COUNT_WORK */
     bool     stage_timing = false;     /* ACN_STAGE_TIMING */
     void read()
@@ -111,6 +113,8 @@ struct Tunables
         if( fetch_walk < 64 ) fetch_walk = 64;
         if( fetch_hard < 64 ) fetch_hard = 64;
         count_work = getenv( "ACN_COUNT_WORK" ) != nullptr;
+        if( const char* e = getenv( "ACN_LEARN_PASSES" ) ) learn_passes = atoi( e ) != 0;
+        if( const char* e = getenv( "ACN_WS_UNIFORM" ) ) ws_uniform = atoi( e ) != 0;
         stage_timing = getenv( "ACN_STAGE_TIMING" ) != nullptr;
         if( lanes < 1 ) lanes = 1;
         if( lanes > 16 ) lanes = 16;
@@ -131,6 +135,8 @@ struct Workspace
     RayTask*    stacks = nullptr;   size_t stack_waves = 0;
     uint32_t    cap[ 5 ] = { 0, 0, 0, 0, 0 };   /* records per queue, WQ_* */
     size_t      bytes = 0;          /* device memory of the queues and stacks */
+    uint64_t    allocs = 0;         /* times this workspace was (re)allocated */
+    bool        trimmed = false;    /* it was already re-allocated smaller once */
 };
 /* the queues of a pipeline run.  Each is sized from its OWN demand per sample position (learned, below): on the wine glass a
  * position leaves 15 deferred shadow rays but 2 shading points, and one common capacity -- the former layout -- made every
@@ -176,6 +182,9 @@ struct acn_scene_handle
     uint64_t hard_rays = 0, walk_steps = 0, walk_rays = 0, shade_hit_recs = 0, host_syncs = 0, private_rays = 0, probe_rays = 0;
     uint32_t flags_seen = 0;                   /* ACN_FLAG_* bits of the last call */
     uint32_t rate_cnt = 0;                     /* positions of the chunk the rates were taken from */
+    double fill_target = 0.7;                  /* fraction of its capacity the fullest queue of a chunk is planned to reach: lowered by
+                                                  every overflow (a redone chunk is lost work), raised slowly by chunks that fit */
+    uint32_t fits_in_a_row = 0;
     double rate[ 5 ] = { 0, 0, 0, 0, 0 };      /* learned: records per sample position a chunk leaves in each queue (WQ_*); 0: not known yet */
     size_t workspace_budget = 0;               /* bytes this handle's queues may take (all lanes together) */
     uint64_t chunks = 0, retries = 0, levels = 0;
@@ -880,7 +889,7 @@ static size_t chunk_for_caps( const acn_scene_handle* h )
     for( int q = 0; q < WQ_N; q++ )
     {
         const double r = h->rate[ q ] > 1e-3 ? h->rate[ q ] : 1e-3;
-        const double c = 0.7 * ( double )h->ws.cap[ q ] / r;
+        const double c = h->fill_target * ( double )h->ws.cap[ q ] / r;
         if( c < chunk ) chunk = c;
     }
     return chunk < 64 ? 64 : ( size_t )chunk;
@@ -893,7 +902,17 @@ static int ensure_workspace( acn_scene_handle* h, size_t n )
     const size_t stack_waves = ( size_t )( h->walk_grid > h->grid ? h->walk_grid : h->grid ) * 4;
     const size_t stack_bytes = stack_waves * h->tun.stack_cap * sizeof( RayTask );
     size_t want[ WQ_N ];
-    if( !rates_known( h ) )
+    bool trim = false;
+    if( h->tun.ws_uniform )
+    {
+        size_t per_rec = wq_bytes[ WQ_HARD_SHADOW ];
+        for( int q = 0; q < WQ_N; q++ ) per_rec += wq_bytes[ q ];
+        size_t recs = budget > stack_bytes ? ( budget - stack_bytes ) / per_rec : 65536;
+        if( recs > 0x7FFFFF00ull ) recs = 0x7FFFFF00ull;
+        for( int q = 0; q < WQ_N; q++ ) want[ q ] = recs;
+        want[ WQ_HARD_SHADOW ] = 2 * recs;
+    }
+    else if( !rates_known( h ) )
     {
         /* starter set: 2^20 records per queue (the deferred-shadow queue twice that), less for a call of a few positions */
         const size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
@@ -911,21 +930,35 @@ static int ensure_workspace( acn_scene_handle* h, size_t n )
     {
         double positions = ( double )( n < ACN_CHUNK_TARGET ? n : ACN_CHUNK_TARGET );
         double bytes = 0;
-        for( int q = 0; q < WQ_N; q++ ) bytes += ( h->rate[ q ] * positions / 0.7 + 65536.0 ) * ( double )wq_bytes[ q ];
+        /* 40 % above what the rates ask for: the rates move a little from frame to frame, and a queue that is a few per
+         * cent short turns one chunk per lane into two (a second chain of launches: c2 36 -> 50 ms) or, worse, makes the
+         * lane re-allocate in the middle of a frame (hipFree synchronises the device: paraffin_lamp 440 -> 700 ms) */
+        const double slack = 1.4;
+        for( int q = 0; q < WQ_N; q++ ) bytes += ( slack * h->rate[ q ] * positions / 0.7 + 65536.0 ) * ( double )wq_bytes[ q ];
         const double room = budget > stack_bytes ? ( double )( budget - stack_bytes ) : 0.0;
         if( bytes > room ) positions *= room / bytes;
         for( int q = 0; q < WQ_N; q++ )
         {
-            double c = h->rate[ q ] * positions / 0.7 + 65536.0;
+            double c = slack * h->rate[ q ] * positions / 0.7 + 65536.0;
             want[ q ] = c > 4.0e9 ? 0xFFFFFF00ull : ( size_t )c;
         }
     }
     for( int q = 0; q < WQ_N; q++ ) { if( want[ q ] < 65536 ) want[ q ] = 65536; if( want[ q ] > 0xFFFFFF00ull ) want[ q ] = 0xFFFFFF00ull; }
-    /* keep what is there while it is large enough (within 20 %: the rates move a little from call to call) */
+    /* keep what is there while it holds what the rates ask for (the slack is for growth, not a reason to re-allocate) */
     bool fits = w.stack_waves >= stack_waves;
-    for( int q = 0; q < WQ_N; q++ ) if( ( double )w.cap[ q ] < 0.8 * ( double )want[ q ] ) fits = false;
+    for( int q = 0; q < WQ_N; q++ ) if( ( double )w.cap[ q ] < ( double )want[ q ] / 1.4 ) fits = false;
+    /* ... and give back what the first, small chunks of a handle over-estimated (their dead slots do not scale): once, when
+     * the rates come from a large chunk and the queues hold 40 % more than those ask for (slack included) */
+    if( fits && rates_known( h ) && !h->tun.ws_uniform && h->rate_cnt >= 32768 && !w.trimmed )
+    {
+        size_t have = 0, need = 0;
+        for( int q = 0; q < WQ_N; q++ ) { have += ( size_t )w.cap[ q ] * wq_bytes[ q ]; need += want[ q ] * wq_bytes[ q ]; }
+        if( ( double )have > 1.4 * ( double )need && have - need > ( ( size_t )1 << 30 ) ) { fits = false; trim = true; }
+    }
     if( fits ) return ACN_OK;
+    const uint64_t allocs_before = w.allocs;
     free_workspace( h );
+    w.allocs = allocs_before + 1;
     for( ;; )
     {
         hipError_t e = hipSuccess;
@@ -941,12 +974,14 @@ static int ensure_workspace( acn_scene_handle* h, size_t n )
         if( e == hipSuccess ) { w.bytes = total; break; }
         ( void )hipGetLastError();
         free_workspace( h );
+        w.allocs = allocs_before + 1;
         bool floor = true;
         for( int q = 0; q < WQ_N; q++ ) { if( want[ q ] > 65536 ) floor = false; want[ q ] = want[ q ] / 2 < 65536 ? 65536 : want[ q ] / 2; }
         if( floor ) return fail( ACN_ERR_DEVICE, std::string( "queue workspace: " ) + hipGetErrorString( e ) );
     }
     for( int q = 0; q < WQ_N; q++ ) w.cap[ q ] = ( uint32_t )want[ q ];
     w.stack_waves = stack_waves;
+    w.trimmed = trim;
     return ACN_OK;
 }
 
@@ -1021,7 +1056,7 @@ static uint32_t walk_passes_of_level( const acn_scene_handle* h, int level )
      * one, are the passes this chunk needs: the last launch of a level finishes whatever is left on the private stacks in
      * any case, so a guess that is too low costs time, never rays.  (A frame without specular surfaces: 2 launches per
      * level instead of 12.) */
-    const uint32_t seen = h->walk_passes_seen[ level ];
+    const uint32_t seen = h->tun.learn_passes ? h->walk_passes_seen[ level ] : 0u;
     if( seen && seen + 1 < passes ) passes = seen + 1;
     return passes;
 }
@@ -1166,12 +1201,13 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     if( rates_known( h ) ) chunk = chunk_for_caps( h );
     else
     {
-        /* the starter queues are small: a first chunk of at most 8192 positions, fewer by a cautious guess -- path-sample hits
-         * quadratic in path_samples (two nested levels), every direct-light sample of every light a deferred shadow ray */
-        chunk = ( size_t )( ( double )h->ws.cap[ WQ_CHILDREN ] / ( ( double )( s + 2 ) * ( s > 16 ? ( double )s / 16.0 : 1.0 ) ) );
-        const size_t by_shadow = ( size_t )( 0.5 * ( double )h->ws.cap[ WQ_HARD_SHADOW ] / ( double )( h->dev.prm.direct_samples * h->n_lights + s + 4 ) );
+        /* the starter queues are small: a first chunk of at most 32 768 positions, fewer by a guess that errs on the safe
+         * side by factors, not orders of magnitude (an overflow costs one small chunk): path-sample hits ~ path_samples per
+         * position, squared from 64 samples on (two nested levels); a quarter of the direct-light samples deferred */
+        chunk = ( size_t )( ( double )h->ws.cap[ WQ_CHILDREN ] / ( ( double )( s + 2 ) * ( s > 64 ? ( double )s / 64.0 : 1.0 ) ) );
+        const size_t by_shadow = ( size_t )( ( double )h->ws.cap[ WQ_HARD_SHADOW ] / ( 0.25 * ( double )( h->dev.prm.direct_samples * h->n_lights + s ) + 4.0 ) );
         if( chunk > by_shadow ) chunk = by_shadow;
-        if( chunk > 8192 ) chunk = 8192;
+        if( chunk > 32768 ) chunk = 32768;
     }
     if( h->tun.chunk ) chunk = h->tun.chunk;
     if( chunk < 64 ) chunk = 64;
@@ -1193,6 +1229,9 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     {
         if( opts && opts->cancel && *opts->cancel ) return fail( ACN_ERR_CANCELLED, "cancelled" );
         uint32_t cnt = ( uint32_t )( ( n_slots - base < chunk ) ? n_slots - base : chunk );
+        /* a chunk that nearly covers what is left takes all of it: the plan is 70 % of the fullest queue, the rest of a lane's
+         * share fits up to 85 % (a second chunk would be another whole chain of launches for a few positions) */
+        if( !h->tun.chunk && ( double )( n_slots - base ) <= ( double )chunk * ( 0.85 / h->fill_target ) ) cnt = ( uint32_t )( n_slots - base );
         int overflow = 0;
         uint32_t fill[ WQ_N ];
         /* the work counters of a chunk that has to be redone must not count twice */
@@ -1204,6 +1243,10 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
             if( cnt <= 1 ) return fail( ACN_ERR_DEVICE, "work queues overflow for a single position: raise ACN_WORKSPACE_MB" );
             if( h->count_work ) HIP_TRY( hipMemcpyAsync( h->d_counters, h->d_counters_keep, sizeof( unsigned long long ) * ACN_CNT_SLOTS, hipMemcpyDeviceToDevice, stream ) );
             h->retries++;
+            /* scenes whose demand per position varies much between chunks (many_spheres p256: 49 of 220 chunks were redone at
+             * a fixed 70 %) plan with more head room */
+            h->fill_target = h->fill_target * 0.85 < 0.3 ? 0.3 : h->fill_target * 0.85;
+            h->fits_in_a_row = 0;
             /* the marks of an overflowed chunk are lower bounds of its demand */
             for( int q = 0; q < WQ_N; q++ ) { const double r = ( double )fill[ q ] / ( double )cnt; if( r > h->rate[ q ] ) h->rate[ q ] = r; }
             for( int level = 0; level <= ACN_MAX_PATH_LEVELS; level++ ) h->walk_passes_seen[ level ] = 0;   /* the full number of passes again */
@@ -1214,6 +1257,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
         }
         h->chunks++;
         base += cnt;
+        if( ++h->fits_in_a_row >= 4 ) { h->fits_in_a_row = 0; h->fill_target = h->fill_target * 1.05 > 0.7 ? 0.7 : h->fill_target * 1.05; }
         if( h->tun.chunk ) continue;
         /* Learn.  A chunk much larger than the one the rates came from replaces them (the dead slots at the ends of the
          * waves' queue reservations do not scale with the chunk, so small chunks over-estimate); otherwise the rates
@@ -1232,11 +1276,11 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
             if( cnt > h->rate_cnt ) h->rate_cnt = cnt;
         }
         const size_t remaining = n_slots - base;
-        if( remaining && chunk_for_caps( h ) < remaining )
+        if( remaining && ( double )chunk_for_caps( h ) * ( 0.85 / h->fill_target ) < ( double )remaining )
         {
             /* more than one further chunk with these queues: re-size them (a no-op when they already are what the budget
              * allows).  Rates that come from a small chunk are trusted for a medium one only. */
-            const size_t target = h->rate_cnt < 32768 ? ( remaining < 65536 ? remaining : ( size_t )65536 ) : remaining;
+            const size_t target = h->rate_cnt < 8192 ? ( remaining < 65536 ? remaining : ( size_t )65536 ) : remaining;
             if( ( st = ensure_workspace( h, target ) ) != ACN_OK ) return st;
         }
         chunk = chunk_for_caps( h );
@@ -1603,16 +1647,16 @@ extern "C" int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms )
 
 extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
 {
-    if( !h || !out || n < 0 || n > 24 || !h->timed ) return fail( ACN_ERR_ARG, "no timed launch" );
+    if( !h || !out || n < 0 || n > 25 || !h->timed ) return fail( ACN_ERR_ARG, "no timed launch" );
     HIP_TRY( hipSetDevice( h->device ) );
     HIP_TRY( hipEventSynchronize( h->ev1 ) );
     double ms[ 4 ] = { 0, 0, 0, 0 };
-    size_t queue_cap = h->ws.cap[ WQ_HARD_SHADOW ], ws_bytes = h->ws.bytes;
+    size_t queue_cap = h->ws.cap[ WQ_HARD_SHADOW ], ws_bytes = h->ws.bytes, ws_allocs = h->ws.allocs;
     std::vector< const acn_scene_handle* > src{ h };
-    if( h->used_lanes ) { src.assign( h->lanes.begin(), h->lanes.begin() + h->lanes_used ); queue_cap = 0; ws_bytes = 0; }   /* stage times: summed over the concurrent lanes of the call */
+    if( h->used_lanes ) { src.assign( h->lanes.begin(), h->lanes.begin() + h->lanes_used ); queue_cap = 0; ws_bytes = 0; ws_allocs = 0; }   /* stage times: summed over the concurrent lanes of the call */
     for( const acn_scene_handle* l : src )
     {
-        if( h->used_lanes ) { queue_cap += l->ws.cap[ WQ_HARD_SHADOW ]; ws_bytes += l->ws.bytes; }
+        if( h->used_lanes ) { queue_cap += l->ws.cap[ WQ_HARD_SHADOW ]; ws_bytes += l->ws.bytes; ws_allocs += l->ws.allocs; }
         for( size_t i = 0; i < l->events_used; i++ )
         {
             float t = 0;
@@ -1622,12 +1666,12 @@ extern "C" int acn_last_stage_ms( acn_scene_handle* h, double* out, int n )
     }
     float total = 0;
     HIP_TRY( hipEventElapsedTime( &total, h->ev0, h->ev1 ) );
-    double v[ 24 ] = { ms[ 0 ], ms[ 1 ], ms[ 2 ], total, ( double )h->launches[ 0 ], ( double )h->launches[ 1 ], ( double )h->launches[ 2 ],
+    double v[ 25 ] = { ms[ 0 ], ms[ 1 ], ms[ 2 ], total, ( double )h->launches[ 0 ], ( double )h->launches[ 1 ], ( double )h->launches[ 2 ],
                        ( double )h->chunks, ( double )h->retries, ( double )h->levels, ( double )h->peak_tasks, ( double )h->peak_children,
                        ( double )queue_cap, ms[ 3 ], ( double )h->launches[ 3 ], ( double )h->hard_rays,
                        ( double )h->walk_rays, ( double )h->shade_hit_recs, ( double )h->host_syncs, ( double )h->walk_steps,
-                       ( double )h->flags_seen, ( double )h->private_rays, ( double )h->probe_rays, ( double )ws_bytes };
-    for( int k = 0; k < n && k < 24; k++ ) out[ k ] = v[ k ];
+                       ( double )h->flags_seen, ( double )h->private_rays, ( double )h->probe_rays, ( double )ws_bytes, ( double )ws_allocs };
+    for( int k = 0; k < n && k < 25; k++ ) out[ k ] = v[ k ];
     return ACN_OK;
 }
 

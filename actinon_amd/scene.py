@@ -286,9 +286,9 @@ class Handle:
         names = ["walk_ms", "shade_ms", "finalize_ms", "total_ms", "walk_launches", "shade_launches", "finalize_launches",
                  "chunks", "retries", "levels", "peak_tasks", "peak_children", "queue_cap", "hard_ms", "hard_launches",
                  "hard_rays", "walk_rays", "path_hits", "host_syncs", "walk_steps", "flags", "private_rays", "probe_rays",
-                 "workspace_bytes"]
-        buf = (C.c_double * 24)()
-        check(hip.acn_last_stage_ms(self.h, buf, 24), "acn_last_stage_ms")
+                 "workspace_bytes", "workspace_allocs"]
+        buf = (C.c_double * 25)()
+        check(hip.acn_last_stage_ms(self.h, buf, 25), "acn_last_stage_ms")
         return dict(zip(names, [float(v) for v in buf]))
 
     def last_counters(self):

@@ -259,7 +259,8 @@ int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms );
  * (8: a pixel contribution exceeded the fixed-point clamp of 16384), [21] rays the walk finished on the waves' private
  * stacks instead of in generation passes, [22] specular rays whose radiance is zero on a hit (depth 0 or intensity below
  * trace_min_intensity, src/scene.c:430) and that were therefore answered by an any-hit probe instead of a walk, [23] bytes
- * of device memory the call's work queues and ray stacks occupy (all lanes). n <= 24. */
+ * of device memory the call's work queues and ray stacks occupy (all lanes), [24] how often they were (re)allocated
+ * since the upload. n <= 25. */
 int acn_last_stage_ms( acn_scene_handle* h, double* out, int n );
 
 /* Work counters of the last render call (rays cast, node visits ...), see DESIGN.md: [0..7] events, [8] flop and
