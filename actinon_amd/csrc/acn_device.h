@@ -526,6 +526,7 @@ template<> struct NodeView< const GNode ACN_CONST* >
 };
 #endif
 #define ACN_NODE( name, expr ) const auto name##_view_ = NodeView< decltype( expr ) >( expr ); const auto name = name##_view_.ptr();
+#define ACN_NODE_UNIFORM( name, expr ) ACN_NODE( name, expr )
 
 template< class NP > DEV bool node_has_env( NP n ) { return ( n->flags & ACN_NODE_HAS_ENVELOPE ) != 0; }
 template< class NP > DEV M3 node_rax( NP n )
@@ -773,7 +774,7 @@ template< class NP, class CT > DEV double simple_leaf_hit_( NP g, V3 rp, V3 rd, 
 
 template< int L, bool SPLIT = false, class SR, class CT > DEV double operand_hit( SR sc, int c, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
 {
-    ACN_NODE( cn, &sc.nodes[ c ] )
+    const auto cn = &sc.nodes[ c ];
     cnt->inc( CNT_OBJ_HIT );
     if( node_has_env( cn ) && !env_ray_hits( cn, rp, rd ) ) return F3_INF;
     if constexpr( L > 1 )
@@ -786,7 +787,7 @@ template< int L, bool SPLIT = false, class SR, class CT > DEV double operand_hit
         }
     }
     if( cn->type != ACN_NEG ) return simple_leaf_hit( cn, rp, rd, want_nor, nor );
-    ACN_NODE( g, &sc.nodes[ cn->child0 ] )
+    const auto g = &sc.nodes[ cn->child0 ];
     cnt->inc( CNT_OBJ_HIT );
     double a = ( node_has_env( g ) && !env_ray_hits( g, rp, rd ) ) ? F3_INF : simple_leaf_hit( g, rp, rd, want_nor, nor );
     if( a < F3_INF && want_nor )
@@ -1493,7 +1494,7 @@ DEV bool prune_exec( NP nodes, ElemP elems, int pc, V3 rp, V3 rd, double limit )
 template< bool NOR, class SC, class CT >
 DEV double element_hit( const SC& sc, int e, V3 rp, V3 rd, V3* nor, int* hit_obj, double limit, CT* cnt )
 {
-    ACN_NODE( n, &sc.nodes[ e ] )
+    ACN_NODE_UNIFORM( n, &sc.nodes[ e ] )
     int type = n->type;
     if( type == ACN_COMPOUND )
     {

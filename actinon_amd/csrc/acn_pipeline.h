@@ -214,6 +214,9 @@ DEV void chunk_prefetch_issue( ChunkP cs, uint32_t* counter, bool enabled, Chunk
 {
     pf.base = 0;
     const uint32_t cur = cs->cur, end = cs->end, spare = cs->spare;
+#ifdef ACN_NO_PREFETCH
+    enabled = false;
+#endif
     pf.issued = enabled && end != 0u && end - cur < 64u && spare == ACN_INVALID_SLOT;
     if( pf.issued ) pf.base = atomicAdd( counter, ( uint32_t )ACN_QCHUNK );
 }

@@ -71,7 +71,7 @@ DEV_SIDE int obj_side_uni( SR sc, int root, bool act, V3 pos, CT* cnt )
     for( ;; )
     {
         /* EVAL( node ) for the lanes with act */
-        ACN_NODE( n, &g.nodes[ node ] )
+        ACN_NODE_UNIFORM( n, &g.nodes[ node ] )
         const int type = n->type;
         const uint32_t nflags = n->flags;
         bool have = true;
@@ -199,7 +199,7 @@ DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp, V3 rd, V3* out_nor, CT* 
     {
         /* ---- EVAL( node, rp, rd ) for the lanes with act ---- */
         ACN_LAP( PH_M_FRAME );
-        ACN_NODE( n, &g.nodes[ node ] )
+        ACN_NODE_UNIFORM( n, &g.nodes[ node ] )
         const int type = n->type;
         const uint32_t nflags = n->flags;
         bool have = true;
