@@ -352,6 +352,7 @@ struct TaskQ
     HardShadow* probes;             /* the level's hard-shadow queue: where probe_push appends */
     uint32_t  probe_cap;
     uint32_t  emit_terms;           /* 0: pixel terms under no sharded sample loop are dropped (ACN_SHARD_SAMPLES, level 0, rank > 0) */
+    uint32_t* flags;                /* the chunk's ACN_FLAG_* word */
 };
 
 /* a ray queue in global memory (k_shade_hits -> k_walk; generation g -> generation g + 1 of k_walk) */
@@ -437,7 +438,7 @@ DEV void probe_push( const TaskQ& tq, ChunkP pcs, bool want, V3 p, V3 d, double 
             HardShadow& h = tq.probes[ slot ];
             h.pos = p; h.d = d; h.limit = limit; h.contrib = contrib; h.pixel = pixel; h.pad = flags;
         }
-        else atomicOr( &tq.counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+        else atomicOr( tq.flags, ACN_FLAG_CHILD_OVERFLOW );
     }
 }
 /* a specular child of shade_hit: onto the ray queue if scene_s_lum would look at its hit, else a probe */
@@ -553,7 +554,7 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
         /* task slots need no dead marks: tasks are only reached through the index lists */
         uint32_t slot = chunk_alloc( tcs, &tq.counts[ QC_TASKS ], emit );
         bool ok = emit && slot < tq.task_cap;
-        if( emit && !ok ) atomicOr( &tq.counts[ QC_FLAGS ], ACN_FLAG_TASK_OVERFLOW );
+        if( emit && !ok ) atomicOr( tq.flags, ACN_FLAG_TASK_OVERFLOW );
         int cls = ok ? size_class( n_direct > n_path ? n_direct : n_path, sc.class0_min ) : -1;
         if( ok )
         {
@@ -577,7 +578,7 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
             if( cls == k )
             {
                 if( is < tq.task_cap ) list[ is ] = slot;
-                else atomicOr( &tq.counts[ QC_FLAGS ], ACN_FLAG_TASK_OVERFLOW );
+                else atomicOr( tq.flags, ACN_FLAG_TASK_OVERFLOW );
             }
         }
     }
@@ -627,7 +628,14 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
  * rebuilt inside (scene arrays are then read through the constant address space, see acn_device.h); p_counts is the
  * counter block of the kernel's level. */
 #define ACN_SCENE_PARAMS  DevScene sc_in, const GNode* __restrict__ p_nodes, const GMat* __restrict__ p_mats, const int32_t* __restrict__ p_elems, const acn_texture* __restrict__ p_textures
-#define ACN_SCENE_VIEW    DevScene sc = sc_in; sc.nodes = ( NodeP )p_nodes; sc.gnodes = ( NodeP )p_nodes; sc.mats = ( MatP )p_mats; sc.elems = ( ElemP )p_elems; sc.textures = ( TexP )p_textures; sc.flags = p_counts + QC_FLAGS; sc.lds_stack = ACN_NO_LDS_STACK;
+#define ACN_SCENE_VIEW    DevScene sc = sc_in; sc.nodes = ( NodeP )p_nodes; sc.gnodes = ( NodeP )p_nodes; sc.mats = ( MatP )p_mats; sc.elems = ( ElemP )p_elems; sc.textures = ( TexP )p_textures; sc.flags = sc_in.flags; sc.lds_stack = ACN_NO_LDS_STACK;
+
+/* One ACN_FLAG_* word per chunk (DevScene.flags: the word of the chunk's first counter block), whatever the path level of
+ * the kernel that raises a flag.  A queue that overflowed means the host will redo the chunk smaller (launch_render):
+ * every later kernel of the chain, enqueued blind, looks at the word first and leaves at once -- the rest of a lost
+ * chunk costs launches, not work (scenes with thousands of hits per position redo 15 - 25 % of their chunks). */
+#define ACN_LEAVE_IF_CHUNK_IS_LOST \
+    if( __builtin_amdgcn_readfirstlane( ( int )*( const volatile uint32_t* )sc_in.flags ) & ( int )( ACN_FLAG_TASK_OVERFLOW | ACN_FLAG_CHILD_OVERFLOW ) ) return;
 
 /* LDS staging of the node array (kernels whose node reads are per-lane: the CSG machines).  The block copies the
  * GNode array into dynamic shared memory once; per-lane node reads then are ds_read instead of global loads. */
@@ -645,7 +653,7 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
 #define ACN_TASKQ_VIEW \
     TaskQ tq; \
     tq.tasks = p_tasks; tq.idx[ 0 ] = p_idx0; tq.idx[ 1 ] = p_idx1; tq.idx[ 2 ] = p_idx2; tq.idx[ 3 ] = p_idx3; \
-    tq.counts = p_counts; tq.task_cap = task_cap; tq.probes = p_probes; tq.probe_cap = probe_cap; tq.emit_terms = probe_emit;
+    tq.counts = p_counts; tq.task_cap = task_cap; tq.probes = p_probes; tq.probe_cap = probe_cap; tq.emit_terms = probe_emit; tq.flags = sc_in.flags;
 
 #ifndef ACN_TRACE_WAVES
 #define ACN_TRACE_WAVES ACN_WALK_WAVES
@@ -658,19 +666,21 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
 #endif
 
 /* The order in which the sample positions of a call are worked off.  A chunk is a contiguous range of SLOTS; slot s
- * stands for position  tile( s / 256 ) * 256 + s % 256  with  tile( t ) = t * mul mod n_tiles  (mul coprime to n_tiles:
- * a bijection).  Tiles of 256 consecutive positions keep neighbouring pixels in one wave; the multiplicative stride
+ * stands for position  tile( s / 64 ) * 64 + s % 64  with  tile( t ) = t * mul mod n_tiles  (mul coprime to n_tiles:
+ * a bijection).  Tiles of 64 consecutive positions keep neighbouring pixels in one wave; the multiplicative stride
  * spreads the tiles of any chunk over the whole frame, so that every chunk of a call sees the same mix of sky, floor
  * and glass -- the queue fill of one chunk then predicts the next one's (launch_render sizes chunks that way). */
+#define ACN_ORDER_SHIFT 6   /* tiles of 64 positions: one step of a wave.  (256 until round 3: a chunk of a scene with thousands of
+                               hits per position is a few hundred positions, and four tiles do not average a frame) */
 struct TileOrder
 {
     uint32_t n;         /* positions of the call */
-    uint32_t n_tiles;   /* ceil( n / 256 ) */
+    uint32_t n_tiles;   /* ceil( n / 64 ) */
     uint32_t mul;
     DEV uint32_t position( uint32_t slot ) const
     {
-        uint32_t tile = ( uint32_t )( ( ( uint64_t )( slot >> 8 ) * mul ) % n_tiles );
-        return ( tile << 8 ) + ( slot & 255u );
+        uint32_t tile = ( uint32_t )( ( ( uint64_t )( slot >> ACN_ORDER_SHIFT ) * mul ) % n_tiles );
+        return ( tile << ACN_ORDER_SHIFT ) + ( slot & ( ( 1u << ACN_ORDER_SHIFT ) - 1u ) );
     }
 };
 
@@ -696,6 +706,7 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
              unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_CHUNK_STATES
+    ACN_LEAVE_IF_CHUNK_IS_LOST
     uint32_t n_in = n_cam;
     if( rays_in ) { n_in = p_counts[ QC_GEN + pass ]; n_in = n_in < in_cap ? n_in : in_cap; }
     n_in = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n_in );
@@ -714,7 +725,7 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
     WalkSink sink;
     sink.priv = n_in <= private_limit;
     sink.stack = stacks + ( size_t )wave * stack_stride; sink.cap = stack_cap; sink.top = 0;
-    sink.out.rays = rays_out; sink.out.counter = p_counts + QC_GEN + pass + 1; sink.out.cap = out_cap; sink.out.flags = p_counts + QC_FLAGS; sink.out.cs = cs + 5;
+    sink.out.rays = rays_out; sink.out.counter = p_counts + QC_GEN + pass + 1; sink.out.cap = out_cap; sink.out.flags = sc_in.flags; sink.out.cs = cs + 5;
     uint32_t* cursor = p_counts + QC_CUR_GEN + pass;
     FetchRange fr;
     range_init( fr, true );
@@ -798,7 +809,7 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
     ACN_LAP( PH_TAIL );
     ACN_PHASE_FLUSH( counters, 0 )
     /* the step bound is a safety net against a loop that does not end; work would be lost, so the call fails */
-    if( !finished && lane == 0 ) atomicOr( p_counts + QC_FLAGS, ACN_FLAG_STACK_OVERFLOW );
+    if( !finished && lane == 0 ) atomicOr( sc_in.flags, ACN_FLAG_STACK_OVERFLOW );
     sink.out.close();
     task_chunks_close( tq, cs );
     wave_stat_add( p_counts + QS_WALK_RAYS, traced );
@@ -816,6 +827,7 @@ void k_shade_hits( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const HitRec* __restrict_
                    unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_CHUNK_STATES
+    ACN_LEAVE_IF_CHUNK_IS_LOST
     uint32_t n = *n_ptr;
     n = n < rec_cap ? n : rec_cap;
     n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
@@ -828,7 +840,7 @@ void k_shade_hits( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const HitRec* __restrict_
     Cnt< COUNT > cnt;
     cnt.clear();
     RayQ rq;
-    rq.rays = rays_out; rq.counter = p_counts + QC_GEN; rq.cap = ray_cap; rq.flags = p_counts + QC_FLAGS; rq.cs = cs + 5;
+    rq.rays = rays_out; rq.counter = p_counts + QC_GEN; rq.cap = ray_cap; rq.flags = sc_in.flags; rq.cs = cs + 5;
     FetchRange fr;
     range_init( fr, n > 0 );
     for( ;; )
@@ -883,6 +895,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
               unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_CHUNK_STATES
+    ACN_LEAVE_IF_CHUNK_IS_LOST
     ACN_SCENE_VIEW
     const auto scp = scene_view< PRUNE >( sc, sc.nodes );   /* the scene as the two root-traversal fast paths see it */
     const ChunkP cs = ACN_CHUNKS_OF_WAVE;                   /* [0] hard shadow, [1] hard path, [2] children */
@@ -1005,7 +1018,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                     }
                     else
                     {
-                        atomicOr( &p_counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+                        atomicOr( sc_in.flags, ACN_FLAG_CHILD_OVERFLOW );
                     }
                 }
             }
@@ -1078,7 +1091,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                     }
                     else
                     {
-                        atomicOr( &p_counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+                        atomicOr( sc_in.flags, ACN_FLAG_CHILD_OVERFLOW );
                     }
                 }
                 /* hard path rays: the transition hit is finished by k_hard_path */
@@ -1094,7 +1107,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                     }
                     else
                     {
-                        atomicOr( &p_counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+                        atomicOr( sc_in.flags, ACN_FLAG_CHILD_OVERFLOW );
                     }
                 }
                 /* the surviving path rays: the next level's queue */
@@ -1112,7 +1125,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                     }
                     else
                     {
-                        atomicOr( &p_counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+                        atomicOr( sc_in.flags, ACN_FLAG_CHILD_OVERFLOW );
                     }
                 }
             }
@@ -1139,6 +1152,7 @@ __global__ __launch_bounds__( 256, ACN_WALK_WAVES )
 void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint32_t cap, uint32_t fetch_batch, uint32_t* __restrict__ p_counts,
                     unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
+    ACN_LEAVE_IF_CHUNK_IS_LOST
     ACN_SCENE_VIEW
     if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
     Cnt< COUNT > cnt;
@@ -1195,6 +1209,7 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
                   uint32_t* __restrict__ p_counts, unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_CHUNK_STATES
+    ACN_LEAVE_IF_CHUNK_IS_LOST
     ACN_SCENE_VIEW
     if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
     Cnt< COUNT > cnt;
@@ -1250,7 +1265,7 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
             }
             else
             {
-                atomicOr( &p_counts[ QC_FLAGS ], ACN_FLAG_CHILD_OVERFLOW );
+                atomicOr( sc_in.flags, ACN_FLAG_CHILD_OVERFLOW );
             }
         }
     }

@@ -203,6 +203,7 @@ struct acn_scene_handle
     std::string lane_error;
     bool used_lanes = false;                   /* the last render call ran through the lanes: statistics are their sums */
     int  lanes_used = 0;                       /* ... the first lanes_used of them */
+    bool one_lane = false;                     /* the last call would have used lanes but did not fit the workspace bound that way */
 };
 #define ACN_LEVEL_BLOCKS ( ACN_MAX_PATH_LEVELS + 1 )
 
@@ -1211,10 +1212,10 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     }
     if( h->tun.chunk ) chunk = h->tun.chunk;
     if( chunk < 64 ) chunk = 64;
-    /* the order of work: tiles of 256 positions in a multiplicative stride over the call (TileOrder) */
+    /* the order of work: tiles of 64 positions in a multiplicative stride over the call (TileOrder) */
     TileOrder order;
     order.n = ( uint32_t )n;
-    order.n_tiles = ( uint32_t )( ( n + 255 ) / 256 );
+    order.n_tiles = ( uint32_t )( ( n + ( ( 1u << ACN_ORDER_SHIFT ) - 1 ) ) >> ACN_ORDER_SHIFT );
     order.mul = 1;
     if( order.n_tiles > 2 )
     {
@@ -1223,7 +1224,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
         while( gcd( m, order.n_tiles ) != 1 ) m += 2;
         order.mul = ( uint32_t )( m % order.n_tiles );
     }
-    const size_t n_slots = ( size_t )order.n_tiles * 256;
+    const size_t n_slots = ( size_t )order.n_tiles << ACN_ORDER_SHIFT;
     size_t base = 0;
     while( base < n_slots )
     {
@@ -1272,7 +1273,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
         {
             /* (also after small chunks: where chunks are small the demand per position is large and the dead slots do not
              * matter; rates that only went up left many_spheres p256 with 532 chunks of 3 900 positions after one spike) */
-            for( int q = 0; q < WQ_N; q++ ) h->rate[ q ] = f_max_host( f_max_host( ( double )fill[ q ] / ( double )cnt, 0.9 * h->rate[ q ] ), 1e-3 );
+            for( int q = 0; q < WQ_N; q++ ) h->rate[ q ] = f_max_host( f_max_host( ( double )fill[ q ] / ( double )cnt, 0.85 * h->rate[ q ] ), 1e-3 );
             if( cnt > h->rate_cnt ) h->rate_cnt = cnt;
         }
         const size_t remaining = n_slots - base;
@@ -1492,8 +1493,33 @@ static int render_dispatch( acn_scene_handle* h, const double* d_pos_xy, size_t 
                             const acn_render_opts* opts, hipStream_t stream )
 {
     int lanes = lanes_for( h, n );
+    /* Lanes pay when a lane's share is ONE chunk: their chains overlap.  A call whose queues cannot hold it in one chunk
+     * per lane within the workspace bound -- scenes with hundreds or thousands of path samples -- does better on one lane
+     * with the whole bound: four times the chunk, a quarter of the chains, and each chunk fills the chip by itself
+     * (diamond 1080p p512, every 16th pixel: 3.69 s on 4 lanes, 2.83 s on one; hanging_lamp 2160p p1024, every 64th:
+     * 21.6 -> 15.4 s; wine_glass 1080p p64, which fits: 71 ms on 4 lanes, 95 on one). */
+    if( lanes > 1 )
+    {
+        const acn_scene_handle* known = nullptr;
+        if( !h->lanes.empty() && rates_known( h->lanes[ 0 ] ) ) known = h->lanes[ 0 ];
+        else if( rates_known( h ) ) known = h;
+        if( known )
+        {
+            double need = 0;
+            for( int q = 0; q < WQ_N; q++ ) need += known->rate[ q ] * ( double )n / 0.7 * ( double )wq_bytes[ q ];
+            /* (sticky by 30 %: rates move a little from call to call, and changing the arrangement re-allocates everything) */
+            if( need > ( h->one_lane ? 0.7 : 1.0 ) * ( double )h->workspace_budget ) lanes = 1;
+        }
+        else if( h->dev.prm.path_samples >= 256 ) lanes = 1;
+    }
     h->used_lanes = false;
-    if( lanes <= 1 ) return launch_render( h, d_pos_xy, first, n, d_out_rgb, opts, stream );
+    h->one_lane = lanes <= 1 && lanes_for( h, n ) > 1;
+    if( lanes <= 1 )
+    {
+        for( acn_scene_handle* l : h->lanes ) free_workspace( l );   /* the bound is the handle's, whoever uses it */
+        return launch_render( h, d_pos_xy, first, n, d_out_rgb, opts, stream );
+    }
+    free_workspace( h );
     return render_lanes( h, lanes, d_pos_xy, first, n, d_out_rgb, opts, stream );
 }
 
