@@ -666,16 +666,17 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
 #endif
 
 /* The order in which the sample positions of a call are worked off.  A chunk is a contiguous range of SLOTS; slot s
- * stands for position  tile( s / 64 ) * 64 + s % 64  with  tile( t ) = t * mul mod n_tiles  (mul coprime to n_tiles:
- * a bijection).  Tiles of 64 consecutive positions keep neighbouring pixels in one wave; the multiplicative stride
+ * stands for position  tile( s / 256 ) * 256 + s % 256  with  tile( t ) = t * mul mod n_tiles  (mul coprime to n_tiles:
+ * a bijection).  Tiles of 256 consecutive positions keep neighbouring pixels in one workgroup; the multiplicative stride
  * spreads the tiles of any chunk over the whole frame, so that every chunk of a call sees the same mix of sky, floor
  * and glass -- the queue fill of one chunk then predicts the next one's (launch_render sizes chunks that way). */
-#define ACN_ORDER_SHIFT 6   /* tiles of 64 positions: one step of a wave.  (256 until round 3: a chunk of a scene with thousands of
-                               hits per position is a few hundred positions, and four tiles do not average a frame) */
+#define ACN_ORDER_SHIFT 8   /* tiles of 256 positions: the four waves of a workgroup work on neighbouring pixels and visit the same nodes
+                               (tiles of 64 mix a small chunk better, but hanging_lamp 2160p p1024 -- 550 KB of nodes -- ran 25 % slower
+                               and the small scenes 1 - 3 %) */
 struct TileOrder
 {
     uint32_t n;         /* positions of the call */
-    uint32_t n_tiles;   /* ceil( n / 64 ) */
+    uint32_t n_tiles;   /* ceil( n / 256 ) */
     uint32_t mul;
     DEV uint32_t position( uint32_t slot ) const
     {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU session 12: parity suite on the chunk-abort / one-lane / finer-order build, then the configs against the round-2 tree
 set -o pipefail
-OUT=$PWD/gpurun_out/s12
+OUT=$PWD/gpurun_out/s13
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$PWD
