@@ -214,7 +214,9 @@ DEV void chunk_prefetch_issue( ChunkP cs, uint32_t* counter, bool enabled, Chunk
 {
     pf.base = 0;
     const uint32_t cur = cs->cur, end = cs->end, spare = cs->spare;
-#ifdef ACN_NO_PREFETCH
+#ifndef ACN_RESERVE_AHEAD   /* off by default: measured three times against the same kernels without it, it costs 0.5 - 0.7 ms of the
+                              71 ms wine_glass frame (the extra LDS reads and the compare of every step) and gains nothing where
+                              the steps are long (profiles/r03/NOTES.md) */
     enabled = false;
 #endif
     pf.issued = enabled && end != 0u && end - cur < 64u && spare == ACN_INVALID_SLOT;
@@ -634,8 +636,11 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
  * the kernel that raises a flag.  A queue that overflowed means the host will redo the chunk smaller (launch_render):
  * every later kernel of the chain, enqueued blind, looks at the word first and leaves at once -- the rest of a lost
  * chunk costs launches, not work (scenes with thousands of hits per position redo 15 - 25 % of their chunks). */
+/* (the word is loaded next to the kernel's input count, one wait for both: a load of its own at the top of every kernel cost
+ * 0.5 ms of the 71 ms frame, ~200 launches of which each is on the chunk's critical path) */
+#define ACN_CHUNK_FLAGS_LOAD const uint32_t chunk_flags_ = *( const uint32_t* )sc_in.flags;
 #define ACN_LEAVE_IF_CHUNK_IS_LOST \
-    if( __builtin_amdgcn_readfirstlane( ( int )*( const volatile uint32_t* )sc_in.flags ) & ( int )( ACN_FLAG_TASK_OVERFLOW | ACN_FLAG_CHILD_OVERFLOW ) ) return;
+    if( __builtin_amdgcn_readfirstlane( ( int )chunk_flags_ ) & ( int )( ACN_FLAG_TASK_OVERFLOW | ACN_FLAG_CHILD_OVERFLOW ) ) return;
 
 /* LDS staging of the node array (kernels whose node reads are per-lane: the CSG machines).  The block copies the
  * GNode array into dynamic shared memory once; per-lane node reads then are ds_read instead of global loads. */
@@ -707,10 +712,11 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
              unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_CHUNK_STATES
-    ACN_LEAVE_IF_CHUNK_IS_LOST
+    ACN_CHUNK_FLAGS_LOAD
     uint32_t n_in = n_cam;
     if( rays_in ) { n_in = p_counts[ QC_GEN + pass ]; n_in = n_in < in_cap ? n_in : in_cap; }
     n_in = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n_in );
+    ACN_LEAVE_IF_CHUNK_IS_LOST
     if( n_in == 0 ) return;
     ACN_SCENE_VIEW
     ACN_TASKQ_VIEW
@@ -828,10 +834,11 @@ void k_shade_hits( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const HitRec* __restrict_
                    unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_CHUNK_STATES
-    ACN_LEAVE_IF_CHUNK_IS_LOST
+    ACN_CHUNK_FLAGS_LOAD
     uint32_t n = *n_ptr;
     n = n < rec_cap ? n : rec_cap;
     n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
+    ACN_LEAVE_IF_CHUNK_IS_LOST
     if( n == 0 ) return;
     fetch_batch = balanced_batch( n, fetch_batch, 64u );
     ACN_SCENE_VIEW
@@ -896,7 +903,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
               unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_CHUNK_STATES
-    ACN_LEAVE_IF_CHUNK_IS_LOST
+    ACN_CHUNK_FLAGS_LOAD
     ACN_SCENE_VIEW
     const auto scp = scene_view< PRUNE >( sc, sc.nodes );   /* the scene as the two root-traversal fast paths see it */
     const ChunkP cs = ACN_CHUNKS_OF_WAVE;                   /* [0] hard shadow, [1] hard path, [2] children */
@@ -914,6 +921,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
     uint32_t n_tasks = p_counts[ QC_CLASS0 + cls ];
     n_tasks = n_tasks < task_cap ? n_tasks : task_cap;
     n_tasks = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n_tasks );
+    ACN_LEAVE_IF_CHUNK_IS_LOST
     fetch_batch = balanced_batch( n_tasks, fetch_batch, ( uint32_t )( 64 / LPT ) );
     uint32_t n_hs = 0, n_hp = 0, n_ch = 0;   /* statistics: records written by this lane */
     auto kill_hs = [ p_hard_shadow ]( uint32_t k ) { p_hard_shadow[ k ].pixel = ACN_INVALID; };
@@ -1153,16 +1161,18 @@ __global__ __launch_bounds__( 256, ACN_WALK_WAVES )
 void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint32_t cap, uint32_t fetch_batch, uint32_t* __restrict__ p_counts,
                     unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
+    ACN_CHUNK_FLAGS_LOAD
+    uint32_t n = p_counts[ QC_HARD_SHADOW ];
+    n = n < cap ? n : cap;
+    n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
     ACN_LEAVE_IF_CHUNK_IS_LOST
+    if( n == 0 ) return;
     ACN_SCENE_VIEW
     if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
     Cnt< COUNT > cnt;
     cnt.clear();
     if constexpr( LDS ) ACN_STAGE_NODES( sc )
     ACN_PHASE_INIT
-    uint32_t n = p_counts[ QC_HARD_SHADOW ];
-    n = n < cap ? n : cap;
-    n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
     fetch_batch = balanced_batch( n, fetch_batch, 64u );
     FetchRange fr;
     range_init( fr, n > 0 );
@@ -1210,7 +1220,12 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
                   uint32_t* __restrict__ p_counts, unsigned long long* __restrict__ accum, unsigned long long* __restrict__ counters )
 {
     ACN_CHUNK_STATES
+    ACN_CHUNK_FLAGS_LOAD
+    uint32_t n = p_counts[ QC_HARD_PATH ];
+    n = n < cap ? n : cap;
+    n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
     ACN_LEAVE_IF_CHUNK_IS_LOST
+    if( n == 0 ) return;
     ACN_SCENE_VIEW
     if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
     Cnt< COUNT > cnt;
@@ -1219,9 +1234,6 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
     ACN_PHASE_INIT
     const ChunkP cs = ACN_CHUNKS_OF_WAVE;
     chunks_init( cs );
-    uint32_t n = p_counts[ QC_HARD_PATH ];
-    n = n < cap ? n : cap;
-    n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
     fetch_batch = balanced_batch( n, fetch_batch, 64u );
     uint32_t n_ch = 0;
     auto kill_ch = [ p_children ]( uint32_t k ) { p_children[ k ].pixel = ACN_INVALID; };

@@ -880,7 +880,7 @@ extern "C" void acn_scene_free( acn_scene_handle* h )
  *     scaled down to the handle's budget (ACN_WORKSPACE_MB; default 8 GiB or a quarter of the free device memory) if that is
  *     less.  The chunk size follows the capacities (launch_render), so a small workspace costs more chunks, not
  *     correctness; if hipMalloc refuses, the request is halved until it fits. */
-#define ACN_CHUNK_TARGET ( ( size_t )1 << 20 )
+#define ACN_CHUNK_TARGET ( ( size_t )1 << 22 )
 #define ACN_STARTER_RECORDS ( ( size_t )1 << 20 )
 static double f_max_host( double a, double b ) { return a > b ? a : b; }
 static bool rates_known( const acn_scene_handle* h ) { return h->rate[ WQ_TASKS ] > 0 || h->rate[ WQ_RAYS ] > 0 || h->rate[ WQ_HARD_SHADOW ] > 0; }
