@@ -89,6 +89,7 @@ struct Tunables
     uint32_t stack_use = 0;            /* ACN_TEST_STACK_USE: slots of a private stack every walk pass but the last uses (tests of the overflow path) */
     bool     debug_chunks = false;     /* ACN_DEBUG_CHUNKS=1: one line per chunk on stderr (size, queue marks, rates, capacities) */
     bool     ws_uniform = false;       /* ACN_WS_UNIFORM=1: every queue gets the same share of the whole bound at once (round 2's layout; diagnostic) */
+    bool     learn_grids = true;       /* ACN_LEARN_GRIDS=0: every launch of a chain gets the full persistent grid, whatever its input was in the last chunk */
     bool     learn_passes = true;      /* ACN_LEARN_PASSES=0: every level gets ACN_WALK_PASSES launches of k_walk, needed or not */
     bool     count_work = false;       /* ACN_COUNT_WORK */
     bool     stage_timing = false;     /* ACN_STAGE_TIMING */
@@ -115,6 +116,7 @@ struct Tunables
         if( fetch_hard < 64 ) fetch_hard = 64;
         count_work = getenv( "ACN_COUNT_WORK" ) != nullptr;
         if( const char* e = getenv( "ACN_LEARN_PASSES" ) ) learn_passes = atoi( e ) != 0;
+        if( const char* e = getenv( "ACN_LEARN_GRIDS" ) ) learn_grids = atoi( e ) != 0;
         if( const char* e = getenv( "ACN_WS_UNIFORM" ) ) ws_uniform = atoi( e ) != 0;
         debug_chunks = getenv( "ACN_DEBUG_CHUNKS" ) != nullptr;
         stage_timing = getenv( "ACN_STAGE_TIMING" ) != nullptr;
@@ -191,6 +193,11 @@ struct acn_scene_handle
     size_t workspace_budget = 0;               /* bytes this handle's queues may take (all lanes together) */
     uint64_t chunks = 0, retries = 0, levels = 0;
     uint64_t peak_tasks = 0, peak_children = 0;
+    /* learned: the input of every launch of the last chunk's chain and the positions of that chunk ( 0: nothing known ) */
+    uint32_t seen_cnt = 0;
+    uint32_t seen_class[ ACN_MAX_PATH_LEVELS + 1 ][ ACN_NCLASS ] = {};
+    uint32_t seen_hs[ ACN_MAX_PATH_LEVELS + 1 ] = {}, seen_hp[ ACN_MAX_PATH_LEVELS + 1 ] = {}, seen_hits[ ACN_MAX_PATH_LEVELS + 1 ] = {};
+    uint32_t seen_gen[ ACN_MAX_PATH_LEVELS + 1 ][ ACN_MAX_WALK_PASSES + 2 ] = {};
     uint32_t walk_passes_seen[ ACN_MAX_PATH_LEVELS + 1 ] = { 0, 0, 0, 0, 0, 0 };   /* learned: passes of a level that had input in the last chunk (0: not known yet) */
     unsigned long long* d_counters_keep = nullptr;   /* the work counters as they were before the current chunk (restored when it is redone) */
     /* concurrent lanes (render_lanes): clones of this handle that share the resident scene and own a stream and a
@@ -1064,6 +1071,21 @@ static uint32_t walk_passes_of_level( const acn_scene_handle* h, int level )
     return passes;
 }
 
+/* Workgroups for a launch whose input had `seen` items in the last chunk of `seen_cnt` positions, scaled to this chunk's `cnt`
+ * positions: enough workgroups for twice that input at `per_wg` items each, at least 16, at most the persistent grid.  The
+ * kernels are persistent and fetch their work through cursors, so ANY grid finishes ANY input: a guess that is too small
+ * costs time, never work.  What it buys: most launches of a chain are small (a generation of a few thousand rays, the
+ * shading tasks of a size class nothing falls into), and a launch of 512 workgroups that has nothing to do still has to
+ * get every one of them onto a chip that the other lanes keep busy -- 0.3 - 1 ms each in the kernel trace of round 2. */
+static unsigned learned_grid( const acn_scene_handle* h, uint32_t seen, uint32_t cnt, uint32_t per_wg, unsigned full )
+{
+    if( !h->tun.learn_grids || h->seen_cnt == 0 ) return full;
+    const double items = 2.0 * ( double )seen * ( double )cnt / ( double )h->seen_cnt + 1.0;
+    double g = items / ( double )per_wg;
+    if( g < 16.0 ) g = 16.0;
+    return g >= ( double )full ? full : ( unsigned )g;
+}
+
 #define ACN_LAUNCH( h, stage, stream, call ) do { int st_ = stage_begin( h, stage, stream ); if( st_ != ACN_OK ) return st_; call; \
     HIP_TRY( hipGetLastError() ); if( ( st_ = stage_end( h, stream ) ) != ACN_OK ) return st_; } while( 0 )
 
@@ -1089,20 +1111,37 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
         /* the path-sample hits of the level before are shaded (level >= 1), then the specular rays walked: generation
          * passes while the generations are large, the rest on the waves' private stacks (k_walk); a level has at most as
          * many generations as its hits have depth left */
-        if( level > 0 ) ACN_LAUNCH( h, 0, stream, acn_launch_shade_hits( f.count, q, stream, s, h->d_accum, h->d_counters ) );
+        LevelQ qg = q;   /* the level's queues with the grid of the launch at hand (learned_grid) */
+        if( level > 0 )
+        {
+            qg.grid = learned_grid( h, h->seen_hits[ level ], cnt, 1024u, h->grid );
+            ACN_LAUNCH( h, 0, stream, acn_launch_shade_hits( f.count, qg, stream, s, h->d_accum, h->d_counters ) );
+        }
         const uint32_t passes = walk_passes_of_level( h, level );
-        LevelQ qw = q;
-        qw.grid = h->walk_grid;
         for( uint32_t pass = 0; pass < passes; pass++ )
-            ACN_LAUNCH( h, 0, stream, acn_launch_walk( f, pass, pass + 1 == passes, qw, lds, stream, s, d_pos_xy, first_pixel, base,
+        {
+            /* the last launch of a level finishes whatever is left on the private stacks: the input of all later generations */
+            uint32_t seen = level == 0 && pass == 0 ? h->seen_cnt : h->seen_gen[ level ][ pass ];
+            if( pass + 1 == passes ) for( uint32_t g = pass + 1; g <= ACN_MAX_WALK_PASSES; g++ ) seen += h->seen_gen[ level ][ g ];
+            qg.grid = level == 0 && pass == 0 ? h->walk_grid : learned_grid( h, seen, cnt, 512u, h->walk_grid );
+            ACN_LAUNCH( h, 0, stream, acn_launch_walk( f, pass, pass + 1 == passes, qg, lds, stream, s, d_pos_xy, first_pixel, base,
                                                        level == 0 && pass == 0 ? cnt : 0u, order, h->d_accum, h->d_counters ) );
-        ACN_LAUNCH( h, 1, stream, acn_launch_shade64( f, q, stream, s, h->d_accum, h->d_counters ) );
-        ACN_LAUNCH( h, 1, stream, acn_launch_shade16( f, q, stream, s, h->d_accum, h->d_counters ) );
-        ACN_LAUNCH( h, 1, stream, acn_launch_shade4( f, q, stream, s, h->d_accum, h->d_counters ) );
-        ACN_LAUNCH( h, 1, stream, acn_launch_shade1( f, q, stream, s, h->d_accum, h->d_counters ) );
-        ACN_LAUNCH( h, 3, stream, acn_launch_hard_shadow( f, q, lds, stream, s, h->d_accum, h->d_counters ) );
+        }
+        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 0 ], cnt, 32u, h->shade_grid );
+        ACN_LAUNCH( h, 1, stream, acn_launch_shade64( f, qg, stream, s, h->d_accum, h->d_counters ) );
+        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 1 ], cnt, 128u, h->shade_grid );
+        ACN_LAUNCH( h, 1, stream, acn_launch_shade16( f, qg, stream, s, h->d_accum, h->d_counters ) );
+        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 2 ], cnt, 512u, h->shade_grid );
+        ACN_LAUNCH( h, 1, stream, acn_launch_shade4( f, qg, stream, s, h->d_accum, h->d_counters ) );
+        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 3 ], cnt, 2048u, h->shade_grid );
+        ACN_LAUNCH( h, 1, stream, acn_launch_shade1( f, qg, stream, s, h->d_accum, h->d_counters ) );
+        qg.grid = learned_grid( h, h->seen_hs[ level ], cnt, 1024u, h->grid );
+        ACN_LAUNCH( h, 3, stream, acn_launch_hard_shadow( f, qg, lds, stream, s, h->d_accum, h->d_counters ) );
         if( level + 1 < levels )   /* the last level casts no path rays (depth <= 10) */
-            ACN_LAUNCH( h, 3, stream, acn_launch_hard_path( f, q, lds, stream, s, h->d_accum, h->d_counters ) );
+        {
+            qg.grid = learned_grid( h, h->seen_hp[ level ], cnt, 1024u, h->grid );
+            ACN_LAUNCH( h, 3, stream, acn_launch_hard_path( f, qg, lds, stream, s, h->d_accum, h->d_counters ) );
+        }
     }
     HIP_TRY( hipMemcpyAsync( h->h_counts, h->d_counts, sizeof( uint32_t ) * QC_N * levels, hipMemcpyDeviceToHost, stream ) );
     HIP_TRY( hipStreamSynchronize( stream ) );
@@ -1169,6 +1208,15 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
             seen[ level ] = ( used == launched && launched > 1 ) ? used + 2 : used;
         }
         for( int level = 0; level < levels; level++ ) h->walk_passes_seen[ level ] = seen[ level ];
+        h->seen_cnt = cnt;
+        for( int level = 0; level < levels; level++ )
+        {
+            const uint32_t* c = h->h_counts + ( size_t )level * QC_N;
+            for( int k = 0; k < ACN_NCLASS; k++ ) h->seen_class[ level ][ k ] = c[ QC_CLASS0 + k ];
+            h->seen_hs[ level ] = c[ QC_HARD_SHADOW ]; h->seen_hp[ level ] = c[ QC_HARD_PATH ];
+            h->seen_hits[ level ] = level > 0 ? h->h_counts[ ( size_t )( level - 1 ) * QC_N + QC_CHILDREN ] : 0u;
+            for( int g = 0; g <= ACN_MAX_WALK_PASSES; g++ ) h->seen_gen[ level ][ g ] = c[ QC_GEN + g ];
+        }
     }
     return ACN_OK;
 }
@@ -1272,6 +1320,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
             /* the marks of an overflowed chunk are lower bounds of its demand */
             for( int q = 0; q < WQ_N; q++ ) { const double r = ( double )fill[ q ] / ( double )cnt; if( r > h->rate[ q ] ) h->rate[ q ] = r; }
             for( int level = 0; level <= ACN_MAX_PATH_LEVELS; level++ ) h->walk_passes_seen[ level ] = 0;   /* the full number of passes again */
+            h->seen_cnt = 0;                                                                                 /* ... and full grids */
             chunk = cnt / 2;
             hipLaunchKernelGGL( k_clear_slots, dim3( ( cnt + 255 ) / 256 ), dim3( 256 ), 0, stream, h->d_accum, ( uint32_t )base, cnt, order );
             HIP_TRY( hipGetLastError() );
