@@ -89,7 +89,9 @@ struct Tunables
     uint32_t stack_use = 0;            /* ACN_TEST_STACK_USE: slots of a private stack every walk pass but the last uses (tests of the overflow path) */
     bool     debug_chunks = false;     /* ACN_DEBUG_CHUNKS=1: one line per chunk on stderr (size, queue marks, rates, capacities) */
     bool     ws_uniform = false;       /* ACN_WS_UNIFORM=1: every queue gets the same share of the whole bound at once (round 2's layout; diagnostic) */
-    bool     learn_grids = true;       /* ACN_LEARN_GRIDS=0: every launch of a chain gets the full persistent grid, whatever its input was in the last chunk */
+    int      learn_grids = 0;          /* ACN_LEARN_GRIDS: 0 every launch of a chain gets the full persistent grid; 1 the grids follow the input of the
+                                        * last chunk (learned_grid); 2 only launches whose input was empty then get a small grid.  Measured, off: see learned_grid */
+    double   grid_passes = 1.0;        /* ACN_GRID_PASSES: a learned grid gives a workgroup this many workgroup-loads of the input it expects (x 1/2: head room) */
     bool     learn_passes = true;      /* ACN_LEARN_PASSES=0: every level gets ACN_WALK_PASSES launches of k_walk, needed or not */
     bool     count_work = false;       /* ACN_COUNT_WORK */
     bool     stage_timing = false;     /* ACN_STAGE_TIMING */
@@ -116,9 +118,10 @@ struct Tunables
         if( fetch_hard < 64 ) fetch_hard = 64;
         count_work = getenv( "ACN_COUNT_WORK" ) != nullptr;
         if( const char* e = getenv( "ACN_LEARN_PASSES" ) ) learn_passes = atoi( e ) != 0;
-        if( const char* e = getenv( "ACN_LEARN_GRIDS" ) ) learn_grids = atoi( e ) != 0;
+        if( const char* e = getenv( "ACN_LEARN_GRIDS" ) ) learn_grids = atoi( e );
         if( const char* e = getenv( "ACN_WS_UNIFORM" ) ) ws_uniform = atoi( e ) != 0;
         debug_chunks = getenv( "ACN_DEBUG_CHUNKS" ) != nullptr;
+        if( const char* e = getenv( "ACN_GRID_PASSES" ) ) { grid_passes = atof( e ); if( !( grid_passes >= 0.25 && grid_passes <= 64.0 ) ) grid_passes = 1.0; }
         stage_timing = getenv( "ACN_STAGE_TIMING" ) != nullptr;
         if( lanes < 1 ) lanes = 1;
         if( lanes > 16 ) lanes = 16;
@@ -1072,16 +1075,22 @@ static uint32_t walk_passes_of_level( const acn_scene_handle* h, int level )
 }
 
 /* Workgroups for a launch whose input had `seen` items in the last chunk of `seen_cnt` positions, scaled to this chunk's `cnt`
- * positions: enough workgroups for twice that input at `per_wg` items each, at least 16, at most the persistent grid.  The
+ * positions: enough workgroups for twice that input at `per_wg` items each -- what ONE workgroup takes on at a time (256
+ * records, 256 / lanes-per-task shading tasks), times ACN_GRID_PASSES -- at least 16, at most the persistent grid.  The
  * kernels are persistent and fetch their work through cursors, so ANY grid finishes ANY input: a guess that is too small
- * costs time, never work.  What it buys: most launches of a chain are small (a generation of a few thousand rays, the
+ * costs time, never work.
+ * OFF by default since the closing measurements of round 3 (profiles/r03/learned_grids_*.txt, four same-box sessions): the
+ * 1080p frame gains 0.2 - 0.7 ms of 70 and C1 0.07 of 1.41 ms, but paraffin_lamp 400x600 loses 15 - 20 % (420 -> 510 ms, in
+ * mode 2 as well, i.e. through launches whose input was empty in the chunk before), hanging_lamp 600x800 2 - 5 % and the 1/8
+ * share of the 1080p frame 2 - 3 %.  What it buys: most launches of a chain are small (a generation of a few thousand rays, the
  * shading tasks of a size class nothing falls into), and a launch of 512 workgroups that has nothing to do still has to
  * get every one of them onto a chip that the other lanes keep busy -- 0.3 - 1 ms each in the kernel trace of round 2. */
 static unsigned learned_grid( const acn_scene_handle* h, uint32_t seen, uint32_t cnt, uint32_t per_wg, unsigned full )
 {
     if( !h->tun.learn_grids || h->seen_cnt == 0 ) return full;
+    if( h->tun.learn_grids == 2 ) return seen == 0 ? 16u : full;
     const double items = 2.0 * ( double )seen * ( double )cnt / ( double )h->seen_cnt + 1.0;
-    double g = items / ( double )per_wg;
+    double g = items / ( ( double )per_wg * h->tun.grid_passes );
     if( g < 16.0 ) g = 16.0;
     return g >= ( double )full ? full : ( unsigned )g;
 }
@@ -1114,7 +1123,7 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
         LevelQ qg = q;   /* the level's queues with the grid of the launch at hand (learned_grid) */
         if( level > 0 )
         {
-            qg.grid = learned_grid( h, h->seen_hits[ level ], cnt, 1024u, h->grid );
+            qg.grid = learned_grid( h, h->seen_hits[ level ], cnt, 256u, h->grid );
             ACN_LAUNCH( h, 0, stream, acn_launch_shade_hits( f.count, qg, stream, s, h->d_accum, h->d_counters ) );
         }
         const uint32_t passes = walk_passes_of_level( h, level );
@@ -1129,19 +1138,19 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
             ACN_LAUNCH( h, 0, stream, acn_launch_walk( f, pass, pass + 1 == passes, qg, lds, stream, s, d_pos_xy, first_pixel, base,
                                                        level == 0 && pass == 0 ? cnt : 0u, order, h->d_accum, h->d_counters ) );
         }
-        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 0 ], cnt, 32u, h->shade_grid );
+        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 0 ], cnt, 4u, h->shade_grid );
         ACN_LAUNCH( h, 1, stream, acn_launch_shade64( f, qg, stream, s, h->d_accum, h->d_counters ) );
-        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 1 ], cnt, 128u, h->shade_grid );
+        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 1 ], cnt, 16u, h->shade_grid );
         ACN_LAUNCH( h, 1, stream, acn_launch_shade16( f, qg, stream, s, h->d_accum, h->d_counters ) );
-        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 2 ], cnt, 512u, h->shade_grid );
+        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 2 ], cnt, 64u, h->shade_grid );
         ACN_LAUNCH( h, 1, stream, acn_launch_shade4( f, qg, stream, s, h->d_accum, h->d_counters ) );
-        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 3 ], cnt, 2048u, h->shade_grid );
+        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 3 ], cnt, 256u, h->shade_grid );
         ACN_LAUNCH( h, 1, stream, acn_launch_shade1( f, qg, stream, s, h->d_accum, h->d_counters ) );
-        qg.grid = learned_grid( h, h->seen_hs[ level ], cnt, 1024u, h->grid );
+        qg.grid = learned_grid( h, h->seen_hs[ level ], cnt, 256u, h->grid );
         ACN_LAUNCH( h, 3, stream, acn_launch_hard_shadow( f, qg, lds, stream, s, h->d_accum, h->d_counters ) );
         if( level + 1 < levels )   /* the last level casts no path rays (depth <= 10) */
         {
-            qg.grid = learned_grid( h, h->seen_hp[ level ], cnt, 1024u, h->grid );
+            qg.grid = learned_grid( h, h->seen_hp[ level ], cnt, 256u, h->grid );
             ACN_LAUNCH( h, 3, stream, acn_launch_hard_path( f, qg, lds, stream, s, h->d_accum, h->d_counters ) );
         }
     }
@@ -1483,6 +1492,16 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
     /* what the caller queued on `stream` before this call must be done before the lanes read the positions */
     HIP_TRY( hipEventRecord( h->ev0, stream ) );
     HIP_TRY( hipEventSynchronize( h->ev0 ) );
+    /* The lanes' queues are (re-)sized here, while the device is idle: hipFree synchronises the device, so lanes that
+     * re-size at the start of their chains wait for each other's chunks (second frame of paraffin_lamp 400x600, whose
+     * queues are trimmed to the rates the first frame learned: 2.1 s instead of 0.45, profiles/r03/frames_paraffin_*.txt) */
+    for( int k = 0; k < lanes; k++ )
+    {
+        acn_scene_handle* l = h->lanes[ k ];
+        l->budget_div = ( size_t )lanes;
+        const size_t cnt = lane_count( n, lanes, k );
+        if( cnt ) { int st = ensure_workspace( l, cnt ); if( st != ACN_OK ) return st; }
+    }
     acn_render_opts lane_opts{};
     if( opts ) lane_opts = *opts;
     std::vector< int > status( lanes, ACN_OK );

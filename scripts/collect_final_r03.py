@@ -16,7 +16,7 @@ if t["kernel_source_hash"] != bench.kernel_source_hash():
     print("WARNING: traffic profile is of other kernel sources:", t["kernel_source_hash"], bench.kernel_source_hash())
 old = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
 json.dump({"wine_glass_1080p": t, "_note": old.get("_note", "")}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
-for f in glob.glob(os.path.join(D, "bench_*.json")) + glob.glob(os.path.join(D, "checksum_*.json")) + [os.path.join(D, x) for x in ("traffic_by_kernel.txt", "tests_gpu.log", "smoke.log")]:
+for f in glob.glob(os.path.join(D, "bench_*.json")) + glob.glob(os.path.join(D, "checksum_*.json")) + [os.path.join(D, x) for x in ("traffic_by_kernel.txt", "tests_gpu.log", "smoke.log", "frames.txt")]:
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, os.path.basename(f)))
 for src, dst in (("stats4", "wine_glass_1080p_4lanes_kernel_stats.csv"), ("stats1", "wine_glass_1080p_1lane_kernel_stats.csv")):

@@ -8,8 +8,6 @@ timeout -k 10 900 python -m pytest tests -m gpu -x -q > $out/tests_gpu.log 2>&1 
 tail -n 2 $out/tests_gpu.log
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1 || { tail -n 5 $out/smoke.log; exit 1; }
 tail -n 2 $out/smoke.log
-timeout -k 10 600 python bench.py --steps 10 --warmup 2 --checksum $out/checksum_wine_glass_1080p.json > $out/bench_wine_glass_1080p.json 2> $out/bench.err || { tail -n 5 $out/bench.err; exit 1; }
-cut -c1-200 $out/bench_wine_glass_1080p.json
 for w in c2 c1 c5 paraffin_lamp; do
   timeout -k 10 300 python bench.py --workload $w --steps 8 --warmup 2 --quick > $out/bench_$w.json 2> $out/bench_$w.err || { tail -n 5 $out/bench_$w.err; exit 1; }
   cut -c1-160 $out/bench_$w.json
@@ -42,6 +40,8 @@ import bench
 t = {"workload": "wine_glass_1080p", "passes": passes, "kernel_source_hash": bench.kernel_source_hash(), "FETCH_SIZE_KB_raw": tot["FETCH_SIZE"], "WRITE_SIZE_KB_raw": tot["WRITE_SIZE"],
      "hbm_bytes_per_step": (fetch_b + write_b) / passes, "fetch_bytes_per_step_x2": fetch_b / passes, "write_bytes_per_step": write_b / passes}
 json.dump(t, open(os.path.join(out, "traffic_wine_glass_1080p.json"), "w"))
+# the headline line below reports this as roofline.traffic (bench.measured_traffic reads profiles/traffic.json)
+tj = json.load(open("profiles/traffic.json")); tj["wine_glass_1080p"] = t; json.dump(tj, open("profiles/traffic.json", "w"), indent=1)
 lines = ["HBM traffic per kernel and frame (PMC FETCH_SIZE x 2 + WRITE_SIZE, two separate rocprofv3 --pmc passes of", "bench.py --steps 4 --warmup 0 --quick: four production passes).  All kernels of one frame: %.1f GB" % ((fetch_b + write_b) / passes / 1e9)]
 for k, (f, w) in sorted(per.items(), key=lambda x: -(x[1][0] * 2 + x[1][1])):
     lines.append("%-40s fetch(x2) %7.2f GB  write %7.2f GB  total %7.2f GB per frame" % (k, f * 2 * 1024 / passes / 1e9, w * 1024 / passes / 1e9, (f * 2 + w) * 1024 / passes / 1e9))
@@ -49,8 +49,17 @@ open(os.path.join(out, "traffic_by_kernel.txt"), "w").write("\n".join(lines) + "
 print("\n".join(lines[:9]))
 PY
 find $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE -name "*.csv" -size +20M -delete
+# the headline line: after the traffic passes, so that it carries the traffic of these very kernels
+timeout -k 10 600 python bench.py --steps 10 --warmup 2 --checksum $out/checksum_wine_glass_1080p.json > $out/bench_wine_glass_1080p.json 2> $out/bench.err || { tail -n 5 $out/bench.err; exit 1; }
+cut -c1-200 $out/bench_wine_glass_1080p.json
 for split in tiles samples; do
   ACN_BENCH_SINGLE_DEVICE=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --split $split > $out/bench_2ranks_rehearsal_$split.json 2> $out/bench_2ranks_$split.err || { tail -n 5 $out/bench_2ranks_$split.err; exit 1; }
   grep '^{' $out/bench_2ranks_rehearsal_$split.json | cut -c1-200
 done
+# steadiness: consecutive frames of the two lamp scenes, this tree and the round-2 tree (if it travelled) on the same box
+for w in paraffin_lamp c5; do
+  echo "== now $w" >> $out/frames.txt; timeout -k 10 200 python scripts/frame_times.py $w 8 2>&1 | tail -n 9 >> $out/frames.txt
+  if [ -d old_r2 ]; then echo "== r02 $w" >> $out/frames.txt; ( cd old_r2 && timeout -k 10 200 python ../scripts/frame_times.py $w 8 2>&1 | tail -n 9 ) >> $out/frames.txt; fi
+done
+cut -c1-110 $out/frames.txt
 echo final done
