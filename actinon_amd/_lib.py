@@ -30,7 +30,7 @@ HIP_SYMBOLS = ["acn_device_count", "acn_scene_upload", "acn_scene_free", "acn_re
 HOST_SYMBOLS = ["acn_rotx", "acn_roty", "acn_rotz", "acn_obj_plane_s_create", "acn_obj_sphere_s_create",
                 "acn_obj_squaroid_s_create_squaroid", "acn_obj_squaroid_s_create_ellipsoid",
                 "acn_obj_squaroid_s_create_hyperboloid1", "acn_obj_squaroid_s_create_hyperboloid2",
-                "acn_obj_squaroid_s_create_cone", "acn_obj_squaroid_s_create_cylinder", "acn_obj_torus_create",
+                "acn_obj_squaroid_s_create_cone", "acn_obj_squaroid_s_create_cylinder", "acn_obj_torus_create", "acn_obj_distance_s_create", "acn_obj_set_distance_function",
                 "acn_obj_pair_inside_s_create_pair", "acn_obj_pair_outside_s_create_pair", "acn_obj_neg_s_create_neg",
                 "acn_obj_scale_s_create_scale", "acn_create_inside_composite", "acn_create_outside_composite",
                 "acn_obj_clone", "acn_obj_discard", "acn_obj_type", "acn_obj_move", "acn_obj_rotate", "acn_obj_scale",
@@ -97,6 +97,10 @@ host.acn_obj_squaroid_s_create_cylinder.argtypes = [C.c_double] * 2
 host.acn_obj_squaroid_s_create_cylinder.restype = vp
 host.acn_obj_torus_create.argtypes = [C.c_double] * 2
 host.acn_obj_torus_create.restype = vp
+host.acn_obj_distance_s_create.argtypes = []
+host.acn_obj_distance_s_create.restype = vp
+host.acn_obj_set_distance_function.argtypes = [vp, C.c_int, C.c_double]
+host.acn_obj_set_distance_function.restype = C.c_int
 for _n in ["acn_obj_pair_inside_s_create_pair", "acn_obj_pair_outside_s_create_pair"]:
     getattr(host, _n).argtypes = [vp, vp]
     getattr(host, _n).restype = vp

@@ -13,6 +13,7 @@ ACN_OK, ACN_ERR_ARG, ACN_ERR_UNSUPPORTED, ACN_ERR_NO_FOV, ACN_ERR_DEVICE, ACN_ER
 NODE_TYPES = {1: "plane", 2: "sphere", 3: "squaroid", 4: "distance", 5: "pair_inside", 6: "pair_outside",
               7: "neg", 8: "scale", 9: "compound"}
 ACN_PLANE, ACN_SPHERE, ACN_SQUAROID, ACN_DISTANCE, ACN_PAIR_INSIDE, ACN_PAIR_OUTSIDE, ACN_NEG, ACN_SCALE, ACN_COMPOUND = range(1, 10)
+ACN_SDF_SPHERE, ACN_SDF_TORUS = 0, 1   # enum acn_sdf_kind
 ACN_NODE_HAS_ENVELOPE = 1
 
 

@@ -13,9 +13,9 @@
  *   built-in functions                                                            src/closures.c:25-604
  * Value model: every script value is a reference-counted box; `def`, list.push, map member creation and
  * compound / scene push deep-copy, function arguments and `for` variables alias (as the reference's sr_s do).
- * Known deviations (documented in DESIGN.md): maps iterate in insertion order (beth: hash order), beth's
- * generic object printing (`?`), beth_object(), read_from_file / write_to_file and string_fa() beyond
- * integer padding are not provided.
+ * Known deviations (documented in DESIGN.md): maps iterate in insertion order (beth: hash order), beth_object() makes the
+ * texture maps / distance functions / obj_distance_s that set_texture_field / set_distance_function take and nothing else, beth's
+ * generic object printing (`?`), read_from_file / write_to_file and string_fa() beyond integer padding are not provided.
  */
 #include <ctype.h>
 #include <math.h>
@@ -45,7 +45,8 @@ typedef struct interp interp;
 enum vtype
 {
     V_BOOL = 1, V_INT, V_FLOAT, V_STR, V_VEC, V_COLOR, V_MAT, V_LIST, V_MAP, V_OBJ, V_SCENE,
-    V_CLOSURE, V_SIG, V_BUILTIN, V_TYPE
+    V_CLOSURE, V_SIG, V_BUILTIN, V_TYPE,
+    V_BETH   /* a texture map or a distance function made by beth_object(): see beth_kinds_g */
 };
 
 /* argument types of a signature (interpreter.c:224-233) */
@@ -73,6 +74,7 @@ struct val
         struct { sigarg* a; size_t n; } sig;
         int builtin;
         int mtype;
+        struct { int kind; acn_v3 c1, c2; double scale, ex_radius; } beth;
     } u;
 };
 
@@ -171,10 +173,15 @@ static const char* type_name( int t )
         case V_VEC: return "v3d";     case V_COLOR: return "color"; case V_MAT: return "m3d";     case V_LIST: return "list";
         case V_MAP: return "map";     case V_OBJ: return "object";  case V_SCENE: return "scene"; case V_CLOSURE: return "func";
         case V_SIG: return "signature"; case V_BUILTIN: return "func"; case V_TYPE: return "type";
+        case V_BETH: return "beth object";
     }
     return "null";
 }
-static const char* vt( const val* v ) { return v ? type_name( v->type ) : "null"; }
+/* What beth_object( name ) can make: the types the object members set_texture_field / set_distance_function take
+ * (textures.c:82-88,130-138; distance.c:30-35,68-74) -- beth's registry of every reflected type is not available. */
+enum { BETH_TXM_PLAIN = 0, BETH_TXM_CHESS, BETH_DISTANCE_SPHERE, BETH_DISTANCE_TORUS, BETH_KINDS };
+static const char* const beth_kinds_g[ BETH_KINDS ] = { "txm_plain_s", "txm_chess_s", "distance_sphere_s", "distance_torus_s" };
+static const char* vt( const val* v ) { return !v ? "null" : v->type == V_BETH ? beth_kinds_g[ v->u.beth.kind ] : type_name( v->type ); }
 
 /* ------------------------------------------------------------------------------------------------------------- */
 /* values                                                                                                        */
@@ -1004,7 +1011,22 @@ static val* call_builtin( ev* e, int id, val** a )
             for( size_t i = 0; i < l; i++ ) if( s[ i ] == '.' || s[ i ] == 'e' || s[ i ] == 'E' ) is_float = 1;
             return is_float ? v_float( strtod( s, NULL ) ) : v_int( strtoll( s, NULL, 10 ) );
         }
-        case BI_BETH_OBJECT: FAIL( e, "beth_object( \"%s\" ): beth's object registry is not available.", a[ 0 ]->u.s ); return NULL;
+        case BI_BETH_OBJECT:   /* closures.c:446-456 */
+        {
+            const char* name = a[ 0 ]->u.s;
+            if( !strcmp( name, "obj_distance_s" ) ) return v_obj( acn_obj_distance_s_create() );
+            for( int k = 0; k < BETH_KINDS; k++ )
+            {
+                if( strcmp( name, beth_kinds_g[ k ] ) ) continue;
+                val* v = v_new( V_BETH );   /* zeroed: colors 0 */
+                v->u.beth.kind = k;
+                v->u.beth.scale = 1.0;      /* textures.c:137 */
+                v->u.beth.ex_radius = 0.5;  /* distance.c:73 */
+                return v;
+            }
+            FAIL( e, "beth_object( \"%s\" ): beth's object registry is not available; txm_plain_s, txm_chess_s, distance_sphere_s, distance_torus_s and obj_distance_s are.", name );
+            return NULL;
+        }
         case BI_GET_TIME: return v_float( ( double )( clock() - e->ip->start ) / CLOCKS_PER_SEC );
     }
     #undef N
@@ -1176,6 +1198,28 @@ static val* vec_member( ev* e, val* front, const char* key )
     return v_float( *c );
 }
 
+/* reflected members of a beth_object() value (interpreter.c:1486-1497: bcore_via get / set by name) */
+static val* beth_member( ev* e, val* front, const char* key )
+{
+    const int kind = front->u.beth.kind;
+    acn_v3* c = NULL; double* f = NULL;
+    if( kind == BETH_TXM_PLAIN && !strcmp( key, "color" ) ) c = &front->u.beth.c1;
+    else if( kind == BETH_TXM_CHESS && !strcmp( key, "color1" ) ) c = &front->u.beth.c1;
+    else if( kind == BETH_TXM_CHESS && !strcmp( key, "color2" ) ) c = &front->u.beth.c2;
+    else if( kind == BETH_TXM_CHESS && !strcmp( key, "scale" ) ) f = &front->u.beth.scale;
+    else if( kind == BETH_DISTANCE_TORUS && !strcmp( key, "ex_radius" ) ) f = &front->u.beth.ex_radius;
+    else FAIL( e, "Object '%s' has no element named '%s'.", vt( front ), key );
+    if( try_tok( e, TK_ASSIGN ) )
+    {
+        val* v = eval_req( e );
+        if( c ) { if( v->type != V_COLOR ) FAIL( e, "Color expected." ); *c = v->u.v; }
+        else    { if( !is_num( v ) ) FAIL( e, "Scalar expected." ); *f = to_f3( v ); }
+        v_unref( v );
+        return v_ref( front );
+    }
+    return c ? v_color( *c ) : v_float( *f );
+}
+
 /* move / rotate / scale shared by map, list, compound and objects */
 static int transform_member( ev* e, val* front, const char* key )
 {
@@ -1309,8 +1353,28 @@ static val* obj_member( ev* e, val* front, const char* key )   /* objects.c:1463
         }
         return v_float( fv );
     }
-    if( !strcmp( key, "set_texture_field" ) || !strcmp( key, "set_distance_function" ) )
-        FAIL( e, "%s: texture / distance objects come from beth_object(), which is not available.", key );
+    if( !strcmp( key, "set_texture_field" ) )   /* objects.c:1510-1517, interpreter.c:1338-1343 */
+    {
+        expect( e, TK_LPAR );
+        val* v = eval( e, NULL );
+        if( !v || v->type != V_BETH || v->u.beth.kind > BETH_TXM_CHESS ) FAIL( e, "Texture map expected." );
+        if( v->u.beth.kind == BETH_TXM_PLAIN ) acn_obj_set_texture_field_plain( o, v->u.beth.c1 );
+        else acn_obj_set_texture_field_chess( o, v->u.beth.c1, v->u.beth.c2, v->u.beth.scale );
+        v_unref( v );
+        expect( e, TK_RPAR );
+        return NULL;
+    }
+    if( !strcmp( key, "set_distance_function" ) )   /* objects.c:1691-1710 */
+    {
+        expect( e, TK_LPAR );
+        if( acn_obj_type( o ) != ACN_DISTANCE ) FAIL( e, "Object '%s' must be 'obj_distance_s'.", vt( front ) );
+        val* v = eval( e, NULL );
+        if( !v || v->type != V_BETH || v->u.beth.kind < BETH_DISTANCE_SPHERE ) FAIL( e, "Object '%s' cannot be used as distance function.", vt( v ) );
+        acn_obj_set_distance_function( o, v->u.beth.kind == BETH_DISTANCE_TORUS ? ACN_SDF_TORUS : ACN_SDF_SPHERE, v->u.beth.ex_radius );
+        v_unref( v );
+        expect( e, TK_RPAR );
+        return NULL;
+    }
     FAIL( e, "Object has no element of name %s.", key );
     return NULL;
 }
@@ -1325,6 +1389,7 @@ static val* eval_member( ev* e, val* front )   /* interpreter.c:1481-1523; front
         case V_LIST:  return list_member( e, front, key );
         case V_OBJ:   return obj_member( e, front, key );
         case V_VEC: case V_COLOR: return vec_member( e, front, key );
+        case V_BETH:  return beth_member( e, front, key );
         default: break;
     }
     FAIL( e, "Object '%s' has no element named '%s'.", vt( front ), key );
@@ -1402,6 +1467,7 @@ static void print_val( const val* v, int indent )
             printf( "%*s</>", indent, "" );
             break;
         case V_OBJ: printf( "<object type=%d/>", acn_obj_type( v->u.obj ) ); break;
+        case V_BETH: printf( "<%s/>", beth_kinds_g[ v->u.beth.kind ] ); break;
         default: printf( "<%s/>", vt( v ) ); break;
     }
 }

@@ -156,6 +156,24 @@ acn_obj* acn_obj_torus_create( double radius1, double radius2 )
     return o;
 }
 
+/* objects.c:853-861 (defaults of the def string), 1691-1710 */
+acn_obj* acn_obj_distance_s_create( void )
+{
+    acn_obj* o = obj_create( ACN_DISTANCE );
+    o->prm[ 0 ] = 1.0;   /* inv_scale */
+    o->cycles   = 200;
+    o->sdf_kind = ACN_SDF_SPHERE;
+    return o;
+}
+int acn_obj_set_distance_function( acn_obj* o, int sdf_kind, double ex_radius )
+{
+    if( !o || o->type != ACN_DISTANCE ) return ACN_ERR_ARG;
+    if( sdf_kind != ACN_SDF_SPHERE && sdf_kind != ACN_SDF_TORUS ) return ACN_ERR_ARG;
+    o->sdf_kind = sdf_kind;
+    o->prm[ 1 ] = sdf_kind == ACN_SDF_TORUS ? ex_radius : 0.0;
+    return ACN_OK;
+}
+
 acn_obj* acn_obj_clone( const acn_obj* o )
 {
     if( !o ) return NULL;
@@ -372,10 +390,12 @@ static double* obj_field( const acn_obj* o, const char* name )
         if( name[ 0 ] == 'c' ) return &m->prm[ 2 ];
         if( name[ 0 ] == 'r' ) return &m->prm[ 3 ];
     }
+    if( o->type == ACN_DISTANCE && !strcmp( name, "inv_scale" ) ) return &m->prm[ 0 ];
     return NULL;
 }
 int acn_obj_get_field( const acn_obj* o, const char* name, double* value )
 {
+    if( o->type == ACN_DISTANCE && !strcmp( name, "cycles" ) ) { *value = ( double )o->cycles; return 1; }
     double* p = obj_field( o, name );
     if( !p ) return 0;
     *value = *p;
@@ -383,6 +403,7 @@ int acn_obj_get_field( const acn_obj* o, const char* name, double* value )
 }
 int acn_obj_set_field( acn_obj* o, const char* name, double value )
 {
+    if( o->type == ACN_DISTANCE && !strcmp( name, "cycles" ) ) { o->cycles = value > 0 ? ( int )value : 0; return 1; }
     double* p = obj_field( o, name );
     if( !p ) return 0;
     *p = value;

@@ -42,6 +42,12 @@ acn_obj* acn_obj_squaroid_s_create_hyperboloid2( double rx, double ry, double rz
 acn_obj* acn_obj_squaroid_s_create_cone( double rx, double ry, double rz );
 acn_obj* acn_obj_squaroid_s_create_cylinder( double rx, double ry );
 acn_obj* acn_obj_torus_create( double radius1, double radius2 );                    /* closures.c:568-591 */
+/* beth_object( "obj_distance_s" ) (objects.c:853-861: inv_scale 1, cycles 200, no envelope) and its set_distance_function
+ * (objects.c:1691-1710) with distance_sphere_s / distance_torus_s (distance.c:30-92): sdf_kind is enum acn_sdf_kind,
+ * ex_radius the torus' ex-planar radius (ignored for the sphere).  A distance object without a function is a unit sphere here
+ * (the reference calls a null pointer).  ACN_ERR_ARG: o is no distance object, or the kind is unknown. */
+acn_obj* acn_obj_distance_s_create( void );
+int      acn_obj_set_distance_function( acn_obj* o, int sdf_kind, double ex_radius );
 acn_obj* acn_obj_pair_inside_s_create_pair( const acn_obj* o1, const acn_obj* o2 );   /* script operator &  */
 acn_obj* acn_obj_pair_outside_s_create_pair( const acn_obj* o1, const acn_obj* o2 );  /* script operator |  */
 acn_obj* acn_obj_neg_s_create_neg( const acn_obj* o1 );                               /* script operator !  */
@@ -85,7 +91,8 @@ void acn_set_envelope_estimator( acn_envelope_estimator_fn fn );
 double acn_obj_radiance( const acn_obj* o );
 void   acn_obj_get_pos( const acn_obj* o, double* pos3 );              /* prp.pos */
 double acn_obj_sphere_s_get_radius( const acn_obj* o );                /* 0 when o is no sphere */
-/* members reachable from scripts as `obj.name`: sphere "radius"; squaroid "a" "b" "c" "r". Return 1 if present. */
+/* members reachable from scripts as `obj.name`: sphere "radius"; squaroid "a" "b" "c" "r"; distance object "inv_scale",
+ * "cycles" (an integer: the value is truncated). Return 1 if present. */
 int    acn_obj_get_field( const acn_obj* o, const char* name, double* value );
 int    acn_obj_set_field( acn_obj* o, const char* name, double value );
 int  acn_obj_get_envelope( const acn_obj* o, double* pos3_radius ); /* 1 if present */

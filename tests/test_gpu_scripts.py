@@ -36,7 +36,9 @@ def read_pnm(path):
 
 
 @pytest.mark.parametrize("script,auto_env", [("csg.acn", A.Scene.AUTOENV_SKIP), ("nested.acn", A.Scene.AUTOENV_GPU),
-                                             ("csg_light.acn", A.Scene.AUTOENV_SKIP)])
+                                             ("csg_light.acn", A.Scene.AUTOENV_SKIP),
+                                             # texture maps / distance functions made by beth_object() in the script
+                                             ("textured.acn", A.Scene.AUTOENV_SKIP)])
 def test_script_scene_parity_with_oracle(oracle, script, auto_env):
     sc = A.Scene.from_script(os.path.join(SCRIPTS, script), auto_env)
     flat = sc.flatten()

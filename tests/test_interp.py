@@ -140,6 +140,55 @@ def nodes_close(a, b, rtol=1e-12):
                 assert va == vb, (i, fname)
 
 
+def test_texture_maps_and_distance_functions_from_scripts(tmp_path):
+    """beth_object() for the types set_texture_field / set_distance_function take (closures.c:446-456, objects.c:1510-1517,
+    1691-1710, textures.c:82-138, distance.c:30-92): tests/scripts/textured.acn is, node for node and texture for texture,
+    the scene tests/scenes_util.py::build_textured makes through the C API -- its torus assembled by hand from an
+    obj_distance_s, a distance_torus_s, scale and envelope where the builder calls create_torus."""
+    import scenes_util as S
+    a = A.Scene.from_script(os.path.join(SCRIPTS, "textured.acn"), SKIP).flatten()
+    b = S.build_textured().flatten()
+    nodes_close(a, b)
+    assert a.c.n_textures == b.c.n_textures == 5
+    for i in range(a.c.n_textures):
+        ta, tb = a.c.textures[i], b.c.textures[i]
+        for fname, _ in type(ta)._fields_:
+            va, vb = getattr(ta, fname), getattr(tb, fname)
+            # (numbers differ by the script language's literal rule, as in nodes_close)
+            assert np.allclose(list(va), list(vb), rtol=1e-12, atol=0) if hasattr(va, "__len__") else (va == vb or math.isclose(va, vb, rel_tol=1e-12)), (i, fname)
+    # reflected members read back; defaults of the def strings; members of the distance object
+    p = tmp_path / "t.acn"
+    p.write_text("""def scene = scene_s;
+def t = beth_object( "txm_chess_s" );
+def d = beth_object( "distance_torus_s" );
+def o = beth_object( "obj_distance_s" );
+def r = [] : t.scale : d.ex_radius : o.cycles : o.inv_scale;
+t.scale = 3; d.ex_radius = 0.25; o.cycles = 50; o.scale( 4 ); t.color2 = color( 0.5, 0.25, 1 );
+r = r : t.scale : d.ex_radius : o.cycles : o.inv_scale : t.color2.y : t.color1.x;
+for x ( in r ) scene.push( create_sphere( x ) );
+o.set_distance_function( beth_object( "distance_sphere_s" ) );
+scene.push( o );
+scene.create_image( "t.pnm" );
+""")
+    f = A.Scene.from_script(p, SKIP).flatten()
+    radii = [f.node(i).prm[0] for i in f.elems_of(f.c.matter_root)]
+    assert radii[:10] == [1.0, 0.5, 200.0, 1.0, 3.0, 0.25, 50.0, 0.25, 0.25, 0.0]
+    last = f.node(f.elems_of(f.c.matter_root)[-1])
+    assert (last.type, last.sdf_kind, last.cycles, last.prm[0]) == (abi.ACN_DISTANCE, abi.ACN_SDF_SPHERE, 50, 0.25)
+    for text, message in (
+            ('def s = create_sphere( 1 ); s.set_texture_field( 3 );', "Texture map expected."),
+            ('def s = create_sphere( 1 ); s.set_texture_field( beth_object( "distance_sphere_s" ) );', "Texture map expected."),
+            ('def s = create_sphere( 1 ); s.set_distance_function( beth_object( "distance_sphere_s" ) );', "must be 'obj_distance_s'"),
+            ('def o = beth_object( "obj_distance_s" ); o.set_distance_function( beth_object( "txm_plain_s" ) );', "'txm_plain_s' cannot be used as distance function"),
+            ('def t = beth_object( "txm_plain_s" ); t.color1 = color( 1, 1, 1 );', "'txm_plain_s' has no element named 'color1'"),
+            ('def t = beth_object( "txm_plain_s" ); t.color = 1;', "Color expected."),
+            ('def t = beth_object( "bcore_arr_s" );', "registry is not available")):
+        p.write_text(text + "\n")
+        with pytest.raises(A.AcnError) as e:
+            A.Scene.from_script(p, SKIP)
+        assert message in str(e.value), (text, str(e.value))
+
+
 @needs_reference
 @pytest.mark.parametrize("name", ["primitives", "wine_glass", "diamond"])
 def test_shipped_scripts_match_direct_builders(name):
