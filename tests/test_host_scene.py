@@ -169,6 +169,35 @@ def test_transform_rules():
         host.acn_obj_discard(o)
 
 
+def test_distance_object_by_hand_equals_the_torus_constructor():
+    """obj_distance_s with its def-string defaults (objects.c:853-861) + set_distance_function (objects.c:1691-1710) + scale +
+    envelope is what create_torus does (closures.c:568-591); the members a script reaches by reflection."""
+    d = host.acn_obj_distance_s_create()
+    v = C.c_double()
+    assert host.acn_obj_get_field(d, b"cycles", C.byref(v)) == 1 and v.value == 200.0
+    assert host.acn_obj_get_field(d, b"inv_scale", C.byref(v)) == 1 and v.value == 1.0
+    assert host.acn_obj_get_field(d, b"radius", C.byref(v)) == 0
+    assert host.acn_obj_set_distance_function(d, abi.ACN_SDF_TORUS, 0.15 / 0.35) == abi.ACN_OK
+    assert host.acn_obj_set_distance_function(d, 7, 0.0) == abi.ACN_ERR_ARG
+    sph = host.acn_obj_sphere_s_create(1.0)
+    assert host.acn_obj_set_distance_function(sph, abi.ACN_SDF_SPHERE, 0.0) == abi.ACN_ERR_ARG
+    host.acn_obj_scale(d, 0.35)
+    host.acn_obj_set_envelope(d, A.v3(0, 0, 0), (0.35 + 0.15) * 1.01)
+    t = host.acn_obj_torus_create(0.35, 0.15)
+    nodes = []
+    for o in (d, t):
+        flat = A.Flat()
+        node = C.c_int32()
+        A.check(host.acn_obj_flatten(o, C.byref(flat.c), C.byref(node)), "flatten")
+        flat._owned = True
+        n = flat.node(node.value)
+        nodes.append((n.type, n.sdf_kind, n.cycles, list(n.prm), n.env_radius, list(n.env_pos), n.flags))
+    assert nodes[0] == nodes[1]
+    assert host.acn_obj_set_field(d, b"cycles", 64.9) == 1 and host.acn_obj_get_field(d, b"cycles", C.byref(v)) == 1 and v.value == 64.0
+    for o in (d, t, sph):
+        host.acn_obj_discard(o)
+
+
 def test_pair_copies_properties_and_drops_envelope():
     a = host.acn_obj_sphere_s_create(1.0)
     host.acn_obj_set_envelope(a, A.v3(0, 0, 0), 1.01)
