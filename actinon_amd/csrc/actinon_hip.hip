@@ -1122,11 +1122,12 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
          * passes while the generations are large, the rest on the waves' private stacks (k_walk); a level has at most as
          * many generations as its hits have depth left */
         LevelQ qg = q;   /* the level's queues with the grid of the launch at hand (learned_grid) */
-        /* a small chunk (<= 2^17 positions) finishes every generation that is no larger than itself on the private stacks:
-         * its generations are too small to be worth a launch each (C1, 120 000 pixels on one lane: 1.41 -> 1.15 ms; the 1/8
-         * share of the 1080p frame, 65 000 positions per lane: 15.2 -> 14.9 ms; chunks of 230 000 positions and more gain
-         * nothing from a higher limit: profiles/r03/private_limit_small_frames.txt) */
-        if( !h->tun.private_limit_set && cnt <= ( 1u << 17 ) && cnt > qg.private_limit ) qg.private_limit = cnt;
+        /* a small chunk (<= 2^17 positions) of a frame without path tracing finishes every generation that is no larger than
+         * itself on the private stacks: its generations are not worth a launch each (C1, 120 000 pixels on one lane: 1.41 ->
+         * 1.15 ms).  With path samples the rule was measured and dropped: the 1/8 share of the 1080p frame 15.2 -> 14.8 ms and
+         * hanging_lamp 600x800 -3 %, but paraffin_lamp 400x600 +8 % -- the rays of a CSG scene are worth redistributing
+         * (profiles/r03/private_limit_small_frames.txt) */
+        if( !h->tun.private_limit_set && h->dev.prm.path_samples == 0 && cnt <= ( 1u << 17 ) && cnt > qg.private_limit ) qg.private_limit = cnt;
         if( level > 0 )
         {
             qg.grid = learned_grid( h, h->seen_hits[ level ], cnt, 256u, h->grid );
