@@ -24,6 +24,11 @@ cli: actinon_amd/bin/actinon_hip
 # one object per kernel family: `make -j` compiles them side by side (acn_launch.h)
 HIP_UNITS := actinon_hip k_shade_64 k_shade_16 k_shade_4 k_shade_1 k_walk_lds k_walk_glb k_walk_count k_walk_count_prune k_hard_shadow k_hard_path
 HIP_OBJS  := $(addprefix $(BUILD)/,$(addsuffix .o,$(HIP_UNITS)))
+# the two production units of k_walk are scheduled for instruction-level parallelism: __launch_bounds__ fixes their occupancy
+# (2 waves per SIMD), which is what the default strategy schedules for (hanging_lamp 600x800 -3 %, everything else equal:
+# profiles/r03/ab_walk_max_ilp_scheduling.txt; same bits: scheduling does not reassociate)
+WALK_SCHED ?= -mllvm -amdgpu-sched-strategy=max-ilp
+$(BUILD)/k_walk_lds.o $(BUILD)/k_walk_glb.o: HIPFLAGS += $(WALK_SCHED)
 $(BUILD)/%.o: actinon_amd/csrc/%.hip $(wildcard actinon_amd/csrc/*.h) include/actinon_hip.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
