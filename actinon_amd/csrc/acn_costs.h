@@ -39,6 +39,7 @@
 #define ACN_F_FOV                20   /* (+) objects.c:619-637 */
 #define ACN_F_OREN_NAYAR         35   /* scene.c:394-416 */
 #define ACN_T_OREN_NAYAR          3   /*   acos, sin, tan */
+#define ACN_F_OREN_NAYAR_DIRECT  17   /* (+) the device's closed form of the same weight in the direct-light loop (oren_nayar_weight_direct): no transcendental */
 #define ACN_F_SEED               18   /* vectors.h:177-190, two calls: 12 integer mul/add + 6 conversions */
 #define ACN_T_SEED                6   /*   frexp */
 #define ACN_F_SHADE_DIFFUSE      40   /* scene.c:526-537 */

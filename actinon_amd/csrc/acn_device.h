@@ -1894,6 +1894,26 @@ DEV double oren_nayar_weight_pre( double weight, double theta_i, double sin_i, d
     return weight * ( on_a + ( on_b * f_max( cos_phi, 0 ) * s1 * ( s2 / c2 ) ) );
 }
 
+/* The same weight for the DIRECT-LIGHT loop (scene.c:556-576), without transcendentals.  There the weight reaches cl_sum and
+ * nothing else -- no intensity, sample count, seed or branch -- so it need not carry the rounding of acos / sin / tan, only
+ * their value.  With w = weight = out_d . nor (unit vectors), theta_r = acos( w ):
+ *     cos( theta_r ) = w,   sin( theta_r ) = sr = sqrt( 1 - w^2 ) = | out_d - nor * w |   (the length v_of_length divides by),
+ *     theta_i < theta_r  <=>  cos_i > w,
+ *     cos_phi = m / sr   with   m = -( out_d - nor * w ) . ray_prj,
+ * hence  max( cos_phi, 0 ) * sin( max ) * tan( min )  =  theta_i >= theta_r:  ( m+ / sr ) * sin_i * ( sr / w ) = m+ * sin_i / w
+ *                                                        theta_i <  theta_r:  ( m+ / sr ) * sr * tan_i       = m+ * tan_i
+ * and the weight is  w * on_a + on_b * m+ * ( cos_i <= w ? sin_i : w * tan_i ):  eleven multiply-adds and a select instead of
+ * acos + sincos + sqrt + two divisions (16 % of k_shade's time, profiles/r03/NOTES.md section 2).  Agrees with
+ * oren_nayar_weight to ~1e-15 relative (5e-9 relative where w < 1e-4, the range in which v_of_length returns its argument
+ * unscaled, vectors.h:151: a sample whose weight is below 1e-4 to begin with); the path loop keeps the exact form because its
+ * weight becomes the child's intensity (scene.c:596-617).  tan_i is used only where cos_i > w > 0. */
+DEV double oren_nayar_weight_direct( double w, double sin_i, double cos_i, double tan_i, double on_a, double on_b, V3 out_d, V3 nor, V3 ray_prj )
+{
+    double m = -v_mlv( v_orthogonal_projection( out_d, nor ), ray_prj );
+    m = f_max( m, 0 );
+    return w * on_a + on_b * m * ( cos_i <= w ? sin_i : w * tan_i );
+}
+
 /* obj_color (objects.c:411-422): texture field if present (textures.c:99-102, 142-148), else prp.color.
  * obj_projection: plane objects.c:514-518, sphere :602-617, distance :893-896. */
 DEV V3 obj_color_dev( const DevScene& sc, int node, V3 pos )

@@ -641,6 +641,18 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
 #define ACN_CHUNK_FLAGS_LOAD const uint32_t chunk_flags_ = *( const uint32_t* )sc_in.flags;
 #define ACN_LEAVE_IF_CHUNK_IS_LOST \
     if( __builtin_amdgcn_readfirstlane( ( int )chunk_flags_ ) & ( int )( ACN_FLAG_TASK_OVERFLOW | ACN_FLAG_CHILD_OVERFLOW ) ) return;
+/* The same for the kernels whose waves depend on each other afterwards (ACN_STAGE_NODES: every wave copies its quarter of the
+ * node array into LDS, then the block synchronises).  Other workgroups of the SAME launch set the word concurrently, so the waves
+ * of one workgroup may read different values; a wave that left alone would leave its quarter of the staged nodes unwritten and
+ * the others would traverse garbage (a spurious ACN_FLAG_STACK_OVERFLOW turned a recoverable lost chunk into a failed call:
+ * ADVICE r03).  Wave 0's reading decides for the whole workgroup. */
+#define ACN_LEAVE_IF_CHUNK_IS_LOST_BLOCK \
+    { \
+        __shared__ uint32_t chunk_lost_; \
+        if( threadIdx.x == 0 ) chunk_lost_ = chunk_flags_ & ( ACN_FLAG_TASK_OVERFLOW | ACN_FLAG_CHILD_OVERFLOW ); \
+        __syncthreads(); \
+        if( chunk_lost_ ) return; \
+    }
 
 /* LDS staging of the node array (kernels whose node reads are per-lane: the CSG machines).  The block copies the
  * GNode array into dynamic shared memory once; per-lane node reads then are ds_read instead of global loads. */
@@ -716,7 +728,7 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
     uint32_t n_in = n_cam;
     if( rays_in ) { n_in = p_counts[ QC_GEN + pass ]; n_in = n_in < in_cap ? n_in : in_cap; }
     n_in = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n_in );
-    ACN_LEAVE_IF_CHUNK_IS_LOST
+    ACN_LEAVE_IF_CHUNK_IS_LOST_BLOCK
     if( n_in == 0 ) return;
     ACN_SCENE_VIEW
     ACN_TASKQ_VIEW
@@ -891,11 +903,65 @@ template< int LPT > DEV uint64_t lcg_stride( uint64_t x )   /* jump by 2*LPT dra
     return lcg_jump_pow2< 1 >( x );
 }
 
+/* Task frames.  A shading point's sample loops run 13 (200 samples on 16 lanes) to hundreds of rounds over ~40 doubles that do
+ * not change from round to round: the surface frame, the Oren-Nayar constants, the light's sampling frame, position, radiance and
+ * colour, the throughput.  Held in registers next to a round's own temporaries they do not fit the 128 VGPRs k_shade runs best
+ * with, and what the allocator spills is exactly these values: round 3's kernel reloaded ~16 of them from SCRATCH in every round
+ * (1.95e8 vector-memory instructions per 1080p frame at ~590 cycles each, 17 GB of spill writes; profiles/r03/NOTES.md section 1).
+ * All LPT lanes of a task hold the SAME values, so they live once per task in LDS instead: the lane with sub == 0 writes the
+ * frame when the task (and each light) is set up, and a round reads a value where it needs it -- a broadcast ds_read, ~64 cycles,
+ * no VMEM slot, no register held across the round.  The accesses are volatile: the compiler neither keeps a value in a register
+ * across uses nor moves a read above the write of another lane (LDS operations of one wave execute in program order).
+ * Narrow classes (LPT < 16: 64 or 256 tasks per workgroup) keep the frame in registers as before: they are 3 % of the time. */
+enum
+{
+    TF_SURFACE_D = 0, TF_RAY_PRJ = 3, TF_SIN_I = 6, TF_COS_I, TF_TAN_I, TF_THETA_I, TF_ON_A, TF_ON_B, TF_DIFF_I,
+    TF_CON = 13,          /* 9: rows of the transposed sampling frame (src_con of the light at hand, then out_con of the path loop) */
+    TF_CYL_HGT = 22, TF_LIGHT_POS = 23, TF_RADIANCE = 26,
+    TF_SCALE = 27,        /* 3: direct loop: Tc * light_color * ( 2 cyl_hgt / direct_samples ), what a deferred sample's c is multiplied with;
+                                path loop: Tchild = Tc * ( 2 / path_samples ) */
+    TF_N = 30
+};
+template< bool IN_LDS > struct TaskFrame;
+template<> struct TaskFrame< true >
+{
+    volatile double ACN_LDS* p;
+    DEV double get( int k ) const { return p[ k ]; }
+    DEV V3 get3( int k ) const { return mk( p[ k ], p[ k + 1 ], p[ k + 2 ] ); }
+    DEV void set( bool writer, int k, double v ) { if( writer ) p[ k ] = v; }
+    DEV void set3( bool writer, int k, V3 v ) { if( writer ) { p[ k ] = v.x; p[ k + 1 ] = v.y; p[ k + 2 ] = v.z; } }
+    /* the writes of the task's first lane are visible to the reads of the others: same wave, program order; the fence keeps the
+     * compiler from moving memory operations across */
+    DEV void publish() const { __builtin_amdgcn_fence( __ATOMIC_SEQ_CST, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
+};
+template<> struct TaskFrame< false >
+{
+    double r[ TF_N ];
+    DEV double get( int k ) const { return r[ k ]; }
+    DEV V3 get3( int k ) const { return mk( r[ k ], r[ k + 1 ], r[ k + 2 ] ); }
+    DEV void set( bool, int k, double v ) { r[ k ] = v; }
+    DEV void set3( bool, int k, V3 v ) { r[ k ] = v.x; r[ k + 1 ] = v.y; r[ k + 2 ] = v.z; }
+    DEV void publish() const {}
+};
+template< class F > DEV M3 frame_con( const F& f )
+{
+    M3 m;
+    m.x = f.get3( TF_CON ); m.y = f.get3( TF_CON + 3 ); m.z = f.get3( TF_CON + 6 );
+    return m;
+}
+template< class F > DEV void frame_set_con( F& f, bool w, const M3& m ) { f.set3( w, TF_CON, m.x ); f.set3( w, TF_CON + 3, m.y ); f.set3( w, TF_CON + 6, m.z ); }
+
 /* LEAF_LIGHTS: every light is a plane / sphere / squaroid-free leaf, so the kernel contains no call into the CSG
  * machine at all (the usual case); otherwise the light hit goes through the generic element test.
  * The tasks are idx[ 0 .. min( p_counts[ QC_CLASS0 + cls ], task_cap ) ) (dead entries skipped); the persistent waves of
- * the grid fetch them through the cursor of the class. */
-template< int LPT, bool COUNT, bool LEAF_LIGHTS, bool PRUNE >
+ * the grid fetch them through the cursor of the class.
+ * PART: 0 both sample loops of a task (one pixel add per task); 1 the direct-light loops only; 2 the path loop only (its LCG
+ * stream starts behind the 2 * direct_samples draws per light of the loops it does not run): the two halves of a fissioned
+ * launch, which share nothing but the task record (see render_chunk). */
+#define ACN_SHADE_BOTH   0
+#define ACN_SHADE_DIRECT 1
+#define ACN_SHADE_PATH   2
+template< int LPT, bool COUNT, bool LEAF_LIGHTS, bool PRUNE, int PART = ACN_SHADE_BOTH >
 __global__ __launch_bounds__( 256, ACN_SHADE_WAVES )
 void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t* __restrict__ idx, int cls, uint32_t task_cap, uint32_t fetch_batch,
               HitRec* __restrict__ p_children, uint32_t child_cap, HardShadow* __restrict__ p_hard_shadow,
@@ -910,14 +976,17 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
     chunks_init( cs );
     ACN_PHASE_INIT
     constexpr int G = 64 / LPT;
+    constexpr bool FRAME_IN_LDS = LPT >= 16;
+    __shared__ __attribute__( ( aligned( 16 ) ) ) double acn_task_frames[ FRAME_IN_LDS ? ( 256 / LPT ) * TF_N : 1 ];
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPT;
     const int grp = lane / LPT;
+    const bool writer = sub == 0;
+    TaskFrame< FRAME_IN_LDS > fr_;
+    if constexpr( FRAME_IN_LDS ) fr_.p = ( volatile double ACN_LDS* )acn_task_frames + ( threadIdx.x / LPT ) * TF_N;
+    const TaskFrame< FRAME_IN_LDS >& F = fr_;
     Cnt< COUNT > cnt;
     cnt.clear();
-    const V3 bg = ld3( sc.prm.background_color );
-    /* "a < max_path_length" as the any-hit limit "a <= path_limit": the largest double below it */
-    const double path_limit = sc.prm.max_path_length < F3_INF ? acn_bits_f64( acn_f64_bits( sc.prm.max_path_length ) - 1ull ) : F3_BIG;
     uint32_t n_tasks = p_counts[ QC_CLASS0 + cls ];
     n_tasks = n_tasks < task_cap ? n_tasks : task_cap;
     n_tasks = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n_tasks );
@@ -942,41 +1011,64 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
         if( LPT == 64 ) slot = __builtin_amdgcn_readfirstlane( slot );
         if( slot == ACN_INVALID ) continue;
         const DTask ACN_CONST& t = ( ( const DTask ACN_CONST* )tasks )[ slot ];
-        const V3 pos = ldc( t.pos ), surface_d = ldc( t.surface_d ), ray_projection = ldc( t.ray_projection );
-        const double theta_i = t.theta_i, on_a = t.on_a, on_b = t.on_b, diffuse_intensity = t.diffuse_intensity;
-        double sin_i = 0, cos_i = 1;   /* loop invariant half of the Oren-Nayar term */
-        if( on_b > 0 ) acn_sincos( theta_i, &sin_i, &cos_i );
+        const V3 pos = ldc( t.pos );   /* the origin of every ray of the task: stays in registers */
+        const double diffuse_intensity = t.diffuse_intensity;
+        const bool oren_nayar = t.on_b > 0;
+        {
+            const V3 surface_d = ldc( t.surface_d );
+            fr_.set3( writer, TF_SURFACE_D, surface_d );
+            fr_.set3( writer, TF_RAY_PRJ, ldc( t.ray_projection ) );
+            const double theta_i = t.theta_i;
+            double sin_i = 0, cos_i = 1;   /* loop invariant half of the Oren-Nayar term */
+            if( oren_nayar ) acn_sincos( theta_i, &sin_i, &cos_i );
+            fr_.set( writer, TF_SIN_I, sin_i ); fr_.set( writer, TF_COS_I, cos_i );
+            fr_.set( writer, TF_TAN_I, cos_i > 0 ? sin_i / cos_i : 0.0 );   /* direct-light loop only, and only where cos_i > weight > 0 */
+            fr_.set( writer, TF_THETA_I, theta_i );
+            fr_.set( writer, TF_ON_A, t.on_a ); fr_.set( writer, TF_ON_B, t.on_b );
+            fr_.set( writer, TF_DIFF_I, diffuse_intensity );
+        }
         uint64_t rv = t.rv;
         V3 lum = mk( 0, 0, 0 );   /* lum_l of scene.c:539, identical in all lanes of the group after each reduction */
         ACN_LAP( PH_FETCH );      /* diagnostic build: k_shade books 10 task fetch / set-up, 4 cap sample, 5 light hit, 6 Oren-Nayar,
                                      7 occlusion, 8 queue appends and sums, 9 path sample, 11 path transition hit */
-
-        /* ---- direct light, scene.c:542-581 ---- */
+        const uint64_t direct_samples = [ & ]() { uint64_t n = ( uint64_t )( sc.prm.direct_samples * diffuse_intensity ); return n == 0 ? ( uint64_t )1 : n; }();
         NodeP light = &sc.nodes[ sc.light_root ];
         const int n_lights = light->child1;
+
+        /* ---- direct light, scene.c:542-581 ---- */
+        if constexpr( PART != ACN_SHADE_PATH )
         for( int li = 0; li < n_lights; li++ )
         {
             int light_idx = __builtin_amdgcn_readfirstlane( sc.elems[ light->child0 + li ] );
             NodeP light_src = &sc.nodes[ light_idx ];
             MatP light_mat = &sc.mats[ light_idx ];
-            V3 fov_d; double cos_rs;
             if( sub == 0 ) cnt.cost( ACN_F_FOV + ACN_F_FRAME );   /* per task and light: booked by one lane of the group */
-            obj_fov_dev( light_src, pos, &fov_d, &cos_rs );
-            const M3 src_frame = m_con_z( fov_d );
-            const V3 src_con_z = src_frame.z;   /* the axis the cap samples are drawn around */
-            M3 src_con = m_transposed( src_frame );
-            double cyl_hgt = 1 - cos_rs;
-            uint64_t direct_samples = ( uint64_t )( sc.prm.direct_samples * diffuse_intensity );
-            direct_samples = ( direct_samples == 0 ) ? 1 : direct_samples;
-            V3 light_pos = ld3( light_src->pos );
-            double radiance = light_mat->radiance;
-            /* root elements no shadow ray of this loop can reach (all of them lie in the light's sampling cone) */
-            const uint64_t skip = root_cone_cull( scp, sc.matter_root, pos, src_con_z, 1.0 - cyl_hgt );
-            const V3 light_color = obj_color_dev( sc, light_idx, light_pos );   /* scene.c:552 */
+            uint64_t skip;
+            V3 light_color;
+            double norm;
+            {
+                V3 fov_d; double cos_rs;
+                obj_fov_dev( light_src, pos, &fov_d, &cos_rs );
+                const M3 src_frame = m_con_z( fov_d );
+                const double cyl_hgt = 1 - cos_rs;
+                /* root elements no shadow ray of this loop can reach (all of them lie in the light's sampling cone; src_frame.z is
+                 * the axis the cap samples are drawn around) */
+                skip = root_cone_cull( scp, sc.matter_root, pos, src_frame.z, 1.0 - cyl_hgt );
+                const V3 light_pos = ld3( light_src->pos );
+                light_color = obj_color_dev( sc, light_idx, light_pos );   /* scene.c:552 */
+                norm = 2.0 * cyl_hgt / direct_samples;
+                frame_set_con( fr_, writer, m_transposed( src_frame ) );
+                fr_.set( writer, TF_CYL_HGT, cyl_hgt );
+                fr_.set3( writer, TF_LIGHT_POS, light_pos );
+                fr_.set( writer, TF_RADIANCE, light_mat->radiance );
+                const V3 Tc = ldc( t.Tc );
+                fr_.set3( writer, TF_SCALE, mk( Tc.x * ( light_color.x * norm ), Tc.y * ( light_color.y * norm ), Tc.z * ( light_color.z * norm ) ) );
+                fr_.publish();
+            }
 
             double s = 0;
             /* ACN_SHARD_SAMPLES (shard_world > 1, level 0 only): this rank's share of the loop; sample j keeps its
-             * place in the LCG stream and the normalisation below keeps the whole loop's n */
+             * place in the LCG stream and the normalisation above keeps the whole loop's n */
             uint64_t j_lo = 0, j_hi = direct_samples;
             uint64_t rv0 = rv;
             if( shard_world > 1 )
@@ -992,8 +1084,9 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 rvj = lcg_stride< LPT >( rvj );
                 cnt.inc( CNT_CAP_SAMPLE );
                 cnt.cost( ACN_F_CAP_SAMPLE, ACN_T_CAP_SAMPLE );
-                V3 out_d = m_mlv( src_con, v_random_sphere_cap( &r, cyl_hgt ) );
-                double weight = v_mlv( out_d, surface_d );
+                const V3 cap = v_random_sphere_cap( &r, F.get( TF_CYL_HGT ) );
+                const V3 out_d = m_mlv( frame_con( F ), cap );
+                double weight = v_mlv( out_d, F.get3( TF_SURFACE_D ) );
                 ACN_LAP( PH_M_LEAF );
                 if( weight <= 0 ) continue;
                 double a;
@@ -1001,27 +1094,35 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 else a = light_hit_call( sc, light_idx, pos, out_d, &cnt );
                 ACN_LAP( PH_M_PAIR );
                 if( a >= F3_INF ) continue;
-                if( on_b > 0 ) { cnt.cost( ACN_F_OREN_NAYAR, ACN_T_OREN_NAYAR ); weight = oren_nayar_weight_pre( weight, theta_i, sin_i, cos_i, on_a, on_b, out_d, surface_d, ray_projection ); }
                 cnt.inc( CNT_SHADOW_RAY );
-                V3 hit_pos = ray_pos( pos, out_d, a );
-                double diff_sqr = v_diff_sqr( hit_pos, light_pos );
-                double local_intensity = ( diff_sqr > 0 ) ? ( radiance / diff_sqr ) : F3_MAG;
-                double c = local_intensity * weight * diffuse_intensity;
                 ACN_LAP( PH_M_FRAME );
                 int occ = root_occluded_fast( scp, sc.matter_root, pos, out_d, a, skip, &cnt );
                 ACN_LAP( PH_M_SIDE );
+                if( occ == 1 ) continue;
+                /* what the sample adds if it is not occluded (scene.c:569-574); the weight of a direct-light sample only scales its
+                 * colour: closed form (oren_nayar_weight_direct).  Computed behind the occlusion test: an occluded sample needs none
+                 * of it, and the test above holds no register for it */
+                if( oren_nayar )
+                {
+                    cnt.cost( ACN_F_OREN_NAYAR_DIRECT );
+                    weight = oren_nayar_weight_direct( weight, F.get( TF_SIN_I ), F.get( TF_COS_I ), F.get( TF_TAN_I ), F.get( TF_ON_A ), F.get( TF_ON_B ), out_d,
+                                                       F.get3( TF_SURFACE_D ), F.get3( TF_RAY_PRJ ) );
+                }
+                V3 hit_pos = ray_pos( pos, out_d, a );
+                double diff_sqr = v_diff_sqr( hit_pos, F.get3( TF_LIGHT_POS ) );
+                double local_intensity = ( diff_sqr > 0 ) ? ( F.get( TF_RADIANCE ) / diff_sqr ) : F3_MAG;
+                double c = local_intensity * weight * F.get( TF_DIFF_I );
                 if( occ == 0 ) { s += c; cnt.cost( ACN_F_DIRECT_TAIL ); }
-                /* hard shadow rays: appended to the queue of k_hard_shadow, which adds c itself if unoccluded */
+                /* hard shadow rays: appended to the queue of k_hard_shadow, which adds the contribution itself if unoccluded */
                 uint32_t hs = chunk_alloc( cs + 0, &p_counts[ QC_HARD_SHADOW ], occ == 2 );
                 if( occ == 2 )
                 {
                     if( hs < hs_cap )
                     {
                         HardShadow& h = p_hard_shadow[ hs ];
-                        double f = c * ( 2.0 * cyl_hgt / direct_samples );
-                        V3 Tc = ldc( t.Tc );
+                        const V3 scale = F.get3( TF_SCALE );
                         h.pos = pos; h.d = out_d; h.limit = a;
-                        h.contrib = mk( Tc.x * ( light_color.x * f ), Tc.y * ( light_color.y * f ), Tc.z * ( light_color.z * f ) );
+                        h.contrib = mk( scale.x * c, scale.y * c, scale.z * c );
                         h.pixel = t.pixel; h.pad = 0;
                         n_hs++;
                     }
@@ -1033,20 +1134,28 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
             }
             rv = lcg00_jump( rv, 2 * direct_samples );
             s = group_sum< LPT >( s );
-            double f = s * ( 2.0 * cyl_hgt / direct_samples );
+            double f = s * norm;
             lum.x += light_color.x * f; lum.y += light_color.y * f; lum.z += light_color.z * f;
             ACN_LAP( PH_SHADE );
         }
+        if constexpr( PART == ACN_SHADE_PATH ) rv = lcg00_jump( rv, 2 * direct_samples * ( uint64_t )n_lights );
 
         /* ---- path tracing, scene.c:584-621 ---- */
+        if constexpr( PART != ACN_SHADE_DIRECT )
         if( sc.prm.path_samples && t.depth > 10 )
         {
             if( sub == 0 ) cnt.cost( ACN_F_FRAME );
-            M3 out_con = m_transposed( m_con_z( surface_d ) );
             uint64_t path_samples = ( uint64_t )( sc.prm.path_samples * diffuse_intensity );
             path_samples = ( path_samples == 0 ) ? 1 : path_samples;
             const double norm = 2.0 / path_samples;
-            const V3 Tchild = v_mlf( ldc( t.Tc ), norm );
+            const V3 bg = ld3( sc.prm.background_color );
+            /* "a < max_path_length" as the any-hit limit "a <= path_limit": the largest double below it */
+            const double path_limit = sc.prm.max_path_length < F3_INF ? acn_bits_f64( acn_f64_bits( sc.prm.max_path_length ) - 1ull ) : F3_BIG;
+            {
+                frame_set_con( fr_, writer, m_transposed( m_con_z( F.get3( TF_SURFACE_D ) ) ) );
+                fr_.set3( writer, TF_SCALE, v_mlf( ldc( t.Tc ), norm ) );
+                fr_.publish();
+            }
             double bsum = 0;
             uint64_t j_lo = 0, j_hi = path_samples;
             uint64_t rv0 = rv;
@@ -1063,8 +1172,9 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 rvj = lcg_stride< LPT >( rvj );
                 cnt.inc( CNT_CAP_SAMPLE );
                 cnt.cost( ACN_F_CAP_SAMPLE, ACN_T_CAP_SAMPLE );
-                V3 out_d = m_mlv( out_con, v_random_sphere_cap( &r, 1.0 ) );
-                double weight = v_mlv( out_d, surface_d );
+                const V3 cap = v_random_sphere_cap( &r, 1.0 );
+                const V3 out_d = m_mlv( frame_con( F ), cap );
+                double weight = v_mlv( out_d, F.get3( TF_SURFACE_D ) );
                 bool live = weight > 0;
                 double a = F3_INF;
                 Trans trans;
@@ -1072,17 +1182,23 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                 bool hard = false;
                 if( live )
                 {
-                    if( on_b > 0 ) { cnt.cost( ACN_F_OREN_NAYAR, ACN_T_OREN_NAYAR ); weight = oren_nayar_weight_pre( weight, theta_i, sin_i, cos_i, on_a, on_b, out_d, surface_d, ray_projection ); }
+                    if( oren_nayar )
+                    {
+                        cnt.cost( ACN_F_OREN_NAYAR, ACN_T_OREN_NAYAR );
+                        weight = oren_nayar_weight_pre( weight, F.get( TF_THETA_I ), F.get( TF_SIN_I ), F.get( TF_COS_I ), F.get( TF_ON_A ), F.get( TF_ON_B ), out_d,
+                                                        F.get3( TF_SURFACE_D ), F.get3( TF_RAY_PRJ ) );
+                    }
                     cnt.cost( ACN_F_PATH_TAIL );
                     ACN_LAP( PH_COMPOUND );
                     a = root_trans_hit_fast( scp, sc.matter_root, pos, out_d, &trans, &hard, &cnt );
                     ACN_LAP( PH_TAIL );
                 }
+                const double child_intensity = weight * diffuse_intensity;
                 bool hit = live && !hard && a < sc.prm.max_path_length;
-                if( live && !hard && !hit ) bsum += weight * diffuse_intensity;
+                if( live && !hard && !hit ) bsum += child_intensity;
                 /* scene_s_lum of a hit with depth - 10 == 0 or too little intensity is zero (scene.c:430): such a hit is not
                  * queued, and such a ray that needs the machine only needs a yes / no (see probe_push) */
-                const bool dark = t.depth - 10 == 0 || weight * diffuse_intensity < sc.prm.trace_min_intensity;
+                const bool dark = t.depth - 10 == 0 || child_intensity < sc.prm.trace_min_intensity;
                 if( dark ) hit = false;
                 const bool probe = hard && dark;
                 if( probe ) hard = false;
@@ -1094,7 +1210,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                     {
                         HardShadow& h = p_hard_shadow[ ps ];
                         h.pos = pos; h.d = out_d; h.limit = path_limit;
-                        h.contrib = v_mld( Tchild, v_mlf( bg, weight * diffuse_intensity ) );   /* k_hard_path's term for a miss */
+                        h.contrib = v_mld( F.get3( TF_SCALE ), v_mlf( bg, child_intensity ) );   /* k_hard_path's term for a miss */
                         h.pixel = t.pixel; h.pad = 0;
                         n_hs++;
                     }
@@ -1110,7 +1226,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                     if( hp < hard_cap )
                     {
                         HardPath& h = p_hard_path[ hp ];
-                        h.pos = pos; h.d = out_d; h.T = Tchild; h.intensity = weight * diffuse_intensity;
+                        h.pos = pos; h.d = out_d; h.T = F.get3( TF_SCALE ); h.intensity = child_intensity;
                         h.depth = t.depth - 10; h.pixel = t.pixel;
                         n_hp++;
                     }
@@ -1126,8 +1242,8 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
                     if( csl < child_cap )
                     {
                         HitRec& c = p_children[ csl ];
-                        c.p = pos; c.d = out_d; c.offs = a; c.exit_nor = trans.exit_nor; c.T = Tchild;
-                        c.intensity = weight * diffuse_intensity;
+                        c.p = pos; c.d = out_d; c.offs = a; c.exit_nor = trans.exit_nor; c.T = F.get3( TF_SCALE );
+                        c.intensity = child_intensity;
                         c.exit_obj = trans.exit_obj; c.enter_obj = trans.enter_obj;
                         c.depth = t.depth - 10; c.pixel = t.pixel;
                         n_ch++;
@@ -1165,7 +1281,7 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
     uint32_t n = p_counts[ QC_HARD_SHADOW ];
     n = n < cap ? n : cap;
     n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
-    ACN_LEAVE_IF_CHUNK_IS_LOST
+    ACN_LEAVE_IF_CHUNK_IS_LOST_BLOCK
     if( n == 0 ) return;
     ACN_SCENE_VIEW
     if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */
@@ -1224,7 +1340,7 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
     uint32_t n = p_counts[ QC_HARD_PATH ];
     n = n < cap ? n : cap;
     n = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )n );
-    ACN_LEAVE_IF_CHUNK_IS_LOST
+    ACN_LEAVE_IF_CHUNK_IS_LOST_BLOCK
     if( n == 0 ) return;
     ACN_SCENE_VIEW
     if( sc_in.lds_stack != ACN_NO_LDS_STACK ) sc.lds_stack = LDS ? sc.n_nodes * ( uint32_t )sizeof( GNode ) : 0u;   /* the CSG stacks follow the staged nodes */

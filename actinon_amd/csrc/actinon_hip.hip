@@ -14,6 +14,7 @@
 #include <condition_variable>
 
 #include "acn_launch.h"
+#include "acn_chunkplan.h"
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* error plumbing */
@@ -190,9 +191,9 @@ struct acn_scene_handle
     uint64_t hard_rays = 0, walk_steps = 0, walk_rays = 0, shade_hit_recs = 0, host_syncs = 0, private_rays = 0, probe_rays = 0;
     uint32_t flags_seen = 0;                   /* ACN_FLAG_* bits of the last call */
     uint32_t rate_cnt = 0;                     /* positions of the chunk the rates were taken from */
-    double fill_target = 0.7;                  /* fraction of its capacity the fullest queue of a chunk is planned to reach: lowered by
-                                                  every overflow (a redone chunk is lost work), raised slowly by chunks that fit */
-    uint32_t fits_in_a_row = 0;
+    acn_chunk_ctl ctl = { 0.7, 0, 0 };         /* acn_chunkplan.h.  fill_target: fraction of its capacity the fullest queue of a chunk is
+                                                  planned to reach: lowered by every overflow (a redone chunk is lost work), raised slowly
+                                                  by chunks that fit */
     double rate[ 5 ] = { 0, 0, 0, 0, 0 };      /* learned: records per sample position a chunk leaves in each queue (WQ_*); 0: not known yet */
     size_t workspace_budget = 0;               /* bytes this handle's queues may take (all lanes together) */
     uint64_t chunks = 0, retries = 0, levels = 0;
@@ -903,7 +904,7 @@ static size_t chunk_for_caps( const acn_scene_handle* h )
     for( int q = 0; q < WQ_N; q++ )
     {
         const double r = h->rate[ q ] > 1e-3 ? h->rate[ q ] : 1e-3;
-        const double c = h->fill_target * ( double )h->ws.cap[ q ] / r;
+        const double c = h->ctl.fill_target * ( double )h->ws.cap[ q ] / r;
         if( c < chunk ) chunk = c;
     }
     return chunk < 64 ? 64 : ( size_t )chunk;
@@ -1197,8 +1198,9 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
         }
         if( mark > 0 && recs < mark ) *dead_share = ( double )( mark - recs ) / ( double )mark;
     }
-    if( flags & ACN_FLAG_STACK_OVERFLOW ) return fail( ACN_ERR_UNSUPPORTED, "device CSG / compound stack overflow (or a walk that did not end)" );
+    /* a lost chunk first: it is redone smaller, and a stack overflow that is real shows again in the retry */
     if( flags & ( ACN_FLAG_TASK_OVERFLOW | ACN_FLAG_CHILD_OVERFLOW ) ) { *overflow = 1; return ACN_OK; }
+    if( flags & ACN_FLAG_STACK_OVERFLOW ) return fail( ACN_ERR_UNSUPPORTED, "device CSG / compound stack overflow (or a walk that did not end)" );
     for( int level = 0; level < levels; level++ )
     {
         const uint32_t* c = h->h_counts + ( size_t )level * QC_N;
@@ -1268,6 +1270,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     h->launches[ 0 ] = h->launches[ 1 ] = h->launches[ 2 ] = h->launches[ 3 ] = 0;
     h->hard_rays = 0; h->walk_steps = 0; h->walk_rays = 0; h->shade_hit_recs = 0; h->host_syncs = 0; h->flags_seen = 0; h->private_rays = 0; h->probe_rays = 0;
     h->chunks = h->retries = h->levels = 0;
+    h->ctl.retry_bound = 0;   /* (a call that ended in the middle of a retry) */
     h->peak_tasks = h->peak_children = 0;
     HIP_TRY( hipMemsetAsync( h->d_counters, 0, sizeof( unsigned long long ) * ACN_CNT_SLOTS, stream ) );
     HIP_TRY( hipEventRecord( h->ev0, stream ) );
@@ -1310,10 +1313,10 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     while( base < n_slots )
     {
         if( opts && opts->cancel && *opts->cancel ) return fail( ACN_ERR_CANCELLED, "cancelled" );
-        uint32_t cnt = ( uint32_t )( ( n_slots - base < chunk ) ? n_slots - base : chunk );
-        /* a chunk that nearly covers what is left takes all of it: the plan is 70 % of the fullest queue, the rest of a lane's
-         * share fits up to 85 % (a second chunk would be another whole chain of launches for a few positions) */
-        if( !h->tun.chunk && ( double )( n_slots - base ) <= ( double )chunk * ( 0.85 / h->fill_target ) ) cnt = ( uint32_t )( n_slots - base );
+        /* the planned chunk; a rest that is predicted to fill no queue beyond 85 % is taken whole (a second chunk would be
+         * another whole chain of launches for a few positions); a retry is at most half of the chunk that overflowed
+         * (acn_chunkplan.h) */
+        uint32_t cnt = acn_ctl_next( &h->ctl, n_slots - base, chunk, h->tun.chunk != 0, rates_known( h ), h->rate, h->ws.cap );
         int overflow = 0;
         uint32_t fill[ WQ_N ];
         double dead_share = 0;
@@ -1323,7 +1326,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
         if( st != ACN_OK ) return st;
         if( h->tun.debug_chunks )
             fprintf( stderr, "[acn chunk] base %zu cnt %u %s target %.2f dead %.2f | fill T %u C %u HS %u HP %u R %u | per pos T %.1f C %.1f HS %.1f HP %.1f R %.1f | rate T %.1f C %.1f HS %.1f HP %.1f R %.1f | cap T %u C %u HS %u HP %u R %u\n",
-                     base, cnt, overflow ? "OVERFLOW" : "ok", h->fill_target, dead_share, fill[ 0 ], fill[ 1 ], fill[ 2 ], fill[ 3 ], fill[ 4 ],
+                     base, cnt, overflow ? "OVERFLOW" : "ok", h->ctl.fill_target, dead_share, fill[ 0 ], fill[ 1 ], fill[ 2 ], fill[ 3 ], fill[ 4 ],
                      fill[ 0 ] / ( double )cnt, fill[ 1 ] / ( double )cnt, fill[ 2 ] / ( double )cnt, fill[ 3 ] / ( double )cnt, fill[ 4 ] / ( double )cnt,
                      h->rate[ 0 ], h->rate[ 1 ], h->rate[ 2 ], h->rate[ 3 ], h->rate[ 4 ], h->ws.cap[ 0 ], h->ws.cap[ 1 ], h->ws.cap[ 2 ], h->ws.cap[ 3 ], h->ws.cap[ 4 ] );
         if( overflow )
@@ -1333,20 +1336,18 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
             h->retries++;
             /* scenes whose demand per position varies much between chunks (many_spheres p256: 49 of 220 chunks were redone at
              * a fixed 70 %) plan with more head room */
-            h->fill_target = h->fill_target * 0.85 < 0.3 ? 0.3 : h->fill_target * 0.85;
-            h->fits_in_a_row = 0;
+            chunk = acn_ctl_overflow( &h->ctl, cnt );
             /* the marks of an overflowed chunk are lower bounds of its demand */
             for( int q = 0; q < WQ_N; q++ ) { const double r = ( double )fill[ q ] / ( double )cnt; if( r > h->rate[ q ] ) h->rate[ q ] = r; }
             for( int level = 0; level <= ACN_MAX_PATH_LEVELS; level++ ) h->walk_passes_seen[ level ] = 0;   /* the full number of passes again */
             h->seen_cnt = 0;                                                                                 /* ... and full grids */
-            chunk = cnt / 2;
             hipLaunchKernelGGL( k_clear_slots, dim3( ( cnt + 255 ) / 256 ), dim3( 256 ), 0, stream, h->d_accum, ( uint32_t )base, cnt, order );
             HIP_TRY( hipGetLastError() );
             continue;
         }
         h->chunks++;
         base += cnt;
-        if( ++h->fits_in_a_row >= 4 ) { h->fits_in_a_row = 0; h->fill_target = h->fill_target * 1.05 > 0.7 ? 0.7 : h->fill_target * 1.05; }
+        acn_ctl_fit( &h->ctl );
         if( h->tun.chunk ) continue;
         /* Learn.  A chunk much larger than the one the rates came from replaces them (the dead slots at the ends of the
          * waves' queue reservations do not scale with the chunk, so small chunks over-estimate); otherwise the rates
@@ -1368,7 +1369,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
             if( cnt > h->rate_cnt ) h->rate_cnt = cnt;
         }
         const size_t remaining = n_slots - base;
-        if( remaining && ( double )chunk_for_caps( h ) * ( 0.85 / h->fill_target ) < ( double )remaining )
+        if( remaining && ( double )chunk_for_caps( h ) * ( 0.85 / h->ctl.fill_target ) < ( double )remaining )
         {
             /* more than one further chunk with these queues: re-size them (a no-op when they already are what the budget
              * allows).  Rates that come from a small chunk are trusted for a medium one only. */
@@ -1556,6 +1557,7 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
     h->launches[ 0 ] = h->launches[ 1 ] = h->launches[ 2 ] = h->launches[ 3 ] = 0;
     h->hard_rays = h->walk_steps = h->walk_rays = h->shade_hit_recs = h->host_syncs = h->private_rays = h->probe_rays = 0; h->flags_seen = 0;
     h->chunks = h->retries = h->levels = 0;
+    h->ctl.retry_bound = 0;   /* (a call that ended in the middle of a retry) */
     h->peak_tasks = h->peak_children = 0;
     for( int k = 0; k < lanes; k++ )
     {
@@ -1580,7 +1582,9 @@ static acn_render_opts opts_of( const acn_render_opts* in )
     acn_render_opts o{};
     if( in )
     {
-        size_t n = in->struct_size ? in->struct_size : offsetof( acn_render_opts, shard_mode );
+        /* 0: a caller that zero-initialises the struct (the memset idiom) and never heard of struct_size -- the word was a
+         * reserved zero in the first published layout, which already had the shard members: the 40-byte base layout */
+        size_t n = in->struct_size ? in->struct_size : ( size_t )ACN_RENDER_OPTS_BASE_SIZE;
         if( n > sizeof( o ) ) n = sizeof( o );
         memcpy( &o, in, n );
     }
@@ -1620,7 +1624,7 @@ static int render_dispatch( acn_scene_handle* h, const double* d_pos_xy, size_t 
     {
         if( rates_known( to ) || !rates_known( from ) ) return;
         for( int q = 0; q < WQ_N; q++ ) to->rate[ q ] = from->rate[ q ];
-        to->rate_cnt = from->rate_cnt; to->fill_target = from->fill_target;
+        to->rate_cnt = from->rate_cnt; to->ctl.fill_target = from->ctl.fill_target;
         for( int level = 0; level <= ACN_MAX_PATH_LEVELS; level++ ) to->walk_passes_seen[ level ] = 0;
     };
     if( lanes <= 1 )

@@ -357,9 +357,13 @@ def main():
         handle.count_work = False
         if world == 1:
             # per kernel family, cleanly: the same pass on ONE lane (no overlapping lanes), per-launch HIP events
+            lanes_before = os.environ.get("ACN_LANES")
             os.environ["ACN_LANES"] = "1"
             h1 = A.Handle(flat, device=local_rank)
-            del os.environ["ACN_LANES"]
+            if lanes_before is None:
+                del os.environ["ACN_LANES"]
+            else:
+                os.environ["ACN_LANES"] = lanes_before
             for timing in (False, True):
                 h1.stage_timing = timing
                 if pos is None:
@@ -481,7 +485,10 @@ def main():
         if args.save_image:
             from actinon_amd._lib import host
             img = host_img.numpy().astype(np.float64) / 256.0 + 0.5 / 256.0
-            host.acn_write_pnm(args.save_image.encode(), img.ctypes.data, W, n_pix // W if args.pixel_stride == 1 else 1)
+            if args.pixel_stride == 1:
+                host.acn_write_pnm(args.save_image.encode(), img.ctypes.data, W, n_pix // W)
+            else:   # every k-th pixel of the raster: not an image any more, one row of the pixels that were rendered
+                host.acn_write_pnm(args.save_image.encode(), img.ctypes.data, img.shape[0], 1)
 
     handle.close()
     if world > 1:

@@ -169,9 +169,10 @@ typedef struct acn_flat_scene
 typedef struct acn_render_opts
 {
     uint32_t flags;
-    uint32_t struct_size;          /* sizeof( acn_render_opts ) as the CALLER was compiled; 0 = the first layout of this struct
-                                      (24 bytes: flags .. stream).  The library reads no member beyond it, so a host built
-                                      against an older header keeps working when members are appended (ACN_RENDER_OPTS_INIT) */
+    uint32_t struct_size;          /* sizeof( acn_render_opts ) as the CALLER was compiled; 0 = the base layout of this struct
+                                      (ACN_RENDER_OPTS_BASE_SIZE = 40 bytes: flags .. reserved2 -- a zero-initialised struct with
+                                      the shard members set keeps its meaning).  The library reads no member beyond it, so a host
+                                      built against an older header keeps working when members are appended (ACN_RENDER_OPTS_INIT) */
     const volatile int* cancel;    /* optional; polled between launches; the SIGINT flag of src/scene.c:893,978 */
     void*    stream;               /* optional hipStream_t; NULL = the handle's own stream */
     uint32_t shard_mode;           /* ACN_SHARD_* */
@@ -179,6 +180,7 @@ typedef struct acn_render_opts
     uint32_t shard_world;          /* 0 or 1: the call is not sharded */
     uint32_t reserved2;
 } acn_render_opts;
+#define ACN_RENDER_OPTS_BASE_SIZE 40
 #define ACN_RENDER_OPTS_INIT { 0u, ( uint32_t )sizeof( acn_render_opts ), 0, 0, ACN_SHARD_NONE, 0u, 0u, 0u }
 
 typedef struct acn_scene_handle acn_scene_handle;

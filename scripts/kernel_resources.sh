@@ -14,9 +14,10 @@ for blk in re.split(r'\n\s+- \.agpr_count', txt)[1:]:
         r = re.search(r'\.' + k + r':\s+(\d+)', blk)
         return int(r.group(1)) if r else -1
     name = re.search(r'\.name:\s+(\S+)', blk).group(1)
-    try: name = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', name], capture_output=True, text=True).stdout.strip().split('(')[0]
+    try: name = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', name], capture_output=True, text=True).stdout.strip()
     except Exception: pass
-    print('%-48s vgpr %3d sgpr %3d spill_v %3d spill_s %3d scratch %5d lds %6d' % (name[-48:], g('vgpr_count'), g('sgpr_count'), g('vgpr_spill_count'), g('sgpr_spill_count'), g('private_segment_fixed_size'), g('group_segment_fixed_size')))
+    m = re.match(r'(?:void )?([A-Za-z_0-9]+(?:<[^>]*>)?)', name)
+    print('%-44s vgpr %3d sgpr %3d spill_v %4d spill_s %4d scratch %5d lds %6d' % (m.group(1) if m else name[:44], g('vgpr_count'), g('sgpr_count'), g('vgpr_spill_count'), g('sgpr_spill_count'), g('private_segment_fixed_size'), g('group_segment_fixed_size')))
 "
 done
 rm -rf $TMP

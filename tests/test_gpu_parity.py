@@ -100,9 +100,11 @@ def test_work_counters_match_oracle_exactly(oracle):
     assert g["trans_rays"] == c["trans_ray"]
     # fp64 work by the cost table of SURVEY.md App. B (actinon_amd/csrc/acn_costs.h): the oracle tallies the reference's
     # algorithm, the device what it executed -- the same events, minus what any-hit shadow tests and envelope pruning
-    # let it skip.  Per-sample shading work (2 transcendentals per cap sample, 3 per Oren-Nayar term, ...) is not skippable.
+    # let it skip.  Per-sample shading work (2 transcendentals per cap sample, ...) is not skippable -- except the three
+    # transcendentals of the Oren-Nayar weight in the DIRECT-light loop, whose closed form needs none
+    # (oren_nayar_weight_direct in acn_device.h: that weight only scales a colour); the path loop keeps the exact form.
     assert 0.5 * c["flop"] < g["flop"] <= c["flop"], (g["flop"], c["flop"])
-    assert 0.97 * c["transc"] <= g["transcendentals"] <= c["transc"], (g["transcendentals"], c["transc"])
+    assert 0.97 * (c["transc"] - 3 * c["oren_nayar"]) <= g["transcendentals"] < c["transc"], (g["transcendentals"], c["transc"], c["oren_nayar"])
 
 
 def test_probe_rays_replace_walks_without_changing_counts(oracle):
