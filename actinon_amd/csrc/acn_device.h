@@ -1015,7 +1015,7 @@ DEV_HIT double obj_ray_hit_dev( SR sc, int root, V3 rp, V3 rd, bool want_nor, V3
                 case ACN_PLANE:    ret_a = plane_ray_hit( ld3( n->pos ), ld3( n->rax + 6 ), rp, rd, want_nor, &ret_n ); break;
                 case ACN_SPHERE:   ret_a = sphere_ray_hit( ld3( n->pos ), n->prm[ 0 ], rp, rd, want_nor, &ret_n ); break;
                 case ACN_SQUAROID: ret_a = squaroid_ray_hit( n, rp, rd, want_nor, &ret_n ); break;
-                default:           ret_a = distance_ray_hit( n, rp, rd, want_nor, &ret_n, cnt ); break;
+                default:           { V3 dn = mk( 0, 0, 0 ); ret_a = distance_ray_hit( n, rp, rd, want_nor, &dn, cnt ); if( want_nor && ret_a < F3_INF ) ret_n = dn; } break;   /* (a real call: only dn's address escapes, ret_n stays in registers) */
             }
             if( want_nor && ret_a < F3_INF && n->surface_roughness > 0 ) ret_n = roughness_normal( n, ret_n, ray_pos( rp, rd, ret_a ) );
             ACN_LAP( PH_M_LEAF );
@@ -1507,7 +1507,12 @@ DEV double element_hit( const SC& sc, int e, V3 rp, V3 rd, V3* nor, int* hit_obj
             }
         }
         ACN_LAP( PH_ROOT_LEAF );
-        double ac = compound_ray_hit_dev( sref( sc ), e, rp, rd, NOR, nor, hit_obj, limit, cnt );
+        /* a real call: it gets the addresses of two locals, so that the caller's normal and hit object -- which every other
+         * branch of this function writes too -- are not forced into scratch memory by an escaping pointer */
+        V3 cn = mk( 0, 0, 0 );
+        int co = *hit_obj;
+        double ac = compound_ray_hit_dev( sref( sc ), e, rp, rd, NOR, &cn, &co, limit, cnt );
+        if( ac < F3_INF ) { if constexpr( NOR ) *nor = cn; *hit_obj = co; }
         ACN_LAP( PH_COMPOUND );
         return ac;
     }

@@ -218,7 +218,7 @@ DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp, V3 rd, V3* out_nor, CT* 
                 if( type == ACN_PLANE )         ret_a = plane_ray_hit( ld3( n->pos ), ld3( n->rax + 6 ), rp, rd, NOR, &ret_n );
                 else if( type == ACN_SPHERE )   ret_a = sphere_ray_hit( ld3( n->pos ), n->prm[ 0 ], rp, rd, NOR, &ret_n );
                 else if( type == ACN_SQUAROID ) ret_a = squaroid_ray_hit( n, rp, rd, NOR, &ret_n );
-                else                            ret_a = distance_ray_hit( n, rp, rd, NOR, &ret_n, cnt );
+                else                            { V3 dn = mk( 0, 0, 0 ); ret_a = distance_ray_hit( n, rp, rd, NOR, &dn, cnt ); if( NOR && ret_a < F3_INF ) ret_n = dn; }   /* (a real call: only dn's address escapes) */
                 if( NOR && ret_a < F3_INF && n->surface_roughness > 0 ) ret_n = roughness_normal( n, ret_n, ray_pos( rp, rd, ret_a ) );
             }
             ACN_LAP( PH_M_LEAF );
