@@ -7,9 +7,11 @@ BUILD    ?= build
 CFLAGS   := -O2 -fPIC -std=gnu11 -Wall -Wno-unused-function -ffp-contract=off -Iinclude
 SHADE_WAVES ?= 4
 WALK_WAVES  ?= 4
-# k_walk: 2 waves per SIMD = 256 VGPRs, no spills (at 4 waves it spills ~800 registers: 100 GB of scratch traffic per
-# 1080p frame for the same speed, profiles/r02/NOTES.md); the hard-ray kernels are faster at 4
-TRACE_WAVES ?= 2
+# k_walk: 4 waves per SIMD (128 VGPRs) since round 4.  Rounds 2 - 3 ran it at 2 (256 VGPRs): with every operand of every pair
+# expanded four times in line the kernel was 1.4 MB of code and spilled ~800 registers at 128.  With the operand loops of
+# pair_hit, the roughness perturbation as a real call and one copy of the root traversal it is 140 KB, spills ~160 at 128, and
+# the two extra waves per SIMD hide more latency than the spills add: 1080p 57.6 -> 53.0 ms, diamond -11 % (profiles/r04/)
+TRACE_WAVES ?= 4
 EXTRA_DEFS ?=
 OPT ?= -O3
 HIPFLAGS := $(EXTRA_DEFS) -DACN_SHADE_WAVES=$(SHADE_WAVES) -DACN_WALK_WAVES=$(WALK_WAVES) -DACN_TRACE_WAVES=$(TRACE_WAVES) $(OPT) -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Iinclude -Iactinon_amd/csrc -std=c++17 -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result

@@ -708,18 +708,31 @@ template< class NP, class CT > DEV int distance_side_( NP o, V3 pos, CT* cnt )  
 }
 #define distance_side( ... ) distance_side_( __VA_ARGS__, cnt )
 
-template< class NP, class CT > DEV V3 roughness_normal_( NP hdr, V3 n, V3 hit_pos, CT* cnt )   /* objects.c:267-282 */
+/* objects.c:267-282.  A REAL call (ACN_ROUGH_INLINE restores the in-line form): the perturbation sits behind every one of the
+ * ~130 places where a hit returns a normal (leaves, operands, pairs, composites), three logarithms and a seed each -- in line
+ * that was 35 - 40 % of k_walk's 1.4 MB of code, in scenes of which most (the wine glass, the diamond, many_spheres) have no rough
+ * surface at all: the hot code was spread over twice the instruction-cache lines it needs.  A rough surface pays a call. */
+#ifdef ACN_ROUGH_INLINE
+#define DEV_ROUGH DEV
+#else
+#define DEV_ROUGH DEVN
+#endif
+DEV_ROUGH V3 roughness_apply( double surface_roughness, V3 n, V3 hit_pos )
 {
-    cnt->cost( ACN_F_ROUGHNESS, ACN_T_ROUGHNESS );
     uint64_t rv = v_random_seed( hit_pos, 1246 );
     double f;
     f = f3_rnd0( &rv ) * 0.99;
-    n.x += hdr->surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
+    n.x += surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
     f = f3_rnd0( &rv ) * 0.99;
-    n.y += hdr->surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
+    n.y += surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
     f = f3_rnd0( &rv ) * 0.99;
-    n.z += hdr->surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
+    n.z += surface_roughness * acn_log( ( 1.0 - f ) / ( 1.0 + f ) );
     return v_of_length( n, 1.0 );
+}
+template< class NP, class CT > DEV V3 roughness_normal_( NP hdr, V3 n, V3 hit_pos, CT* cnt )
+{
+    cnt->cost( ACN_F_ROUGHNESS, ACN_T_ROUGHNESS );
+    return roughness_apply( hdr->surface_roughness, n, hit_pos );
 }
 #define roughness_normal( ... ) roughness_normal_( __VA_ARGS__, cnt )
 
@@ -747,17 +760,23 @@ template< class NP, class CT > DEV int simple_leaf_side_( NP g, V3 pos, CT* cnt 
 template< int L, class SR, class NP, class CT > DEV int pair_side( SR sc, NP n, V3 pos, CT* cnt );
 template< int L, bool SPLIT = false, class SR, class NP, class CT > DEV double pair_hit( SR sc, NP n, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt );
 
+/* An operand that is NEG( simple leaf ) goes through the SAME copy of the leaf code as a plain one (the leaf's node is selected,
+ * the sign applied afterwards): every in-line copy of an operand is one plane / sphere / squaroid routine, not two. */
 template< int L, class SR, class CT > DEV int operand_side( SR sc, int c, V3 pos, CT* cnt )
 {
-    ACN_NODE( cn, &sc.nodes[ c ] )
+    const auto cn = &sc.nodes[ c ];
     cnt->inc( CNT_SIDE );
     if( node_has_env( cn ) && env_side( cn, pos ) == 1 ) return 1;
     if constexpr( L > 1 ) { if( cn->flags & ACN_GFLAG_LEAF_PAIR ) return pair_side< L - 1 >( sc, cn, pos, cnt ); }
-    if( cn->type != ACN_NEG ) return simple_leaf_side( cn, pos );
-    ACN_NODE( g, &sc.nodes[ cn->child0 ] )
-    cnt->inc( CNT_SIDE );
-    int r = ( node_has_env( g ) && env_side( g, pos ) == 1 ) ? 1 : simple_leaf_side( g, pos );
-    return -r;
+    const bool neg = cn->type == ACN_NEG;
+    const auto g = neg ? &sc.nodes[ cn->child0 ] : cn;
+    if( neg )
+    {
+        cnt->inc( CNT_SIDE );
+        if( node_has_env( g ) && env_side( g, pos ) == 1 ) return -1;
+    }
+    const int r = simple_leaf_side( g, pos );
+    return neg ? -r : r;
 }
 
 template< class NP, class CT > DEV double simple_leaf_hit_( NP g, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
@@ -786,11 +805,15 @@ template< int L, bool SPLIT = false, class SR, class CT > DEV double operand_hit
             return a;
         }
     }
-    if( cn->type != ACN_NEG ) return simple_leaf_hit( cn, rp, rd, want_nor, nor );
-    const auto g = &sc.nodes[ cn->child0 ];
-    cnt->inc( CNT_OBJ_HIT );
-    double a = ( node_has_env( g ) && !env_ray_hits( g, rp, rd ) ) ? F3_INF : simple_leaf_hit( g, rp, rd, want_nor, nor );
-    if( a < F3_INF && want_nor )
+    const bool neg = cn->type == ACN_NEG;
+    const auto g = neg ? &sc.nodes[ cn->child0 ] : cn;
+    if( neg )
+    {
+        cnt->inc( CNT_OBJ_HIT );
+        if( node_has_env( g ) && !env_ray_hits( g, rp, rd ) ) return F3_INF;
+    }
+    const double a = simple_leaf_hit( g, rp, rd, want_nor, nor );
+    if( neg && a < F3_INF && want_nor )
     {
         *nor = v_neg( *nor );                                                                  /* objects.c:1329-1339 */
         if( cn->surface_roughness > 0 ) *nor = roughness_normal( cn, *nor, ray_pos( rp, rd, a ) );
@@ -805,47 +828,98 @@ template< int L, class SR, class NP, class CT > DEV int pair_side( SR sc, NP n, 
     return operand_side< L >( sc, n->child1, pos, cnt ) == want ? want : -want;
 }
 
-/* the pair's hit without its own envelope test and roughness (the caller does both, as for any node).
- * SPLIT: the pair node is the same in every lane (a root element tested by k_shade): the alternating walk then branches on
- * which operand's turn it is instead of selecting the operand's index per lane -- the operand nodes stay wave-uniform,
- * i.e. scalar loads from the scalar cache instead of a dozen per-lane vector loads (~1500 cycles each under load) per step. */
+/* the pair's hit without its own envelope test and roughness (the caller does both, as for any node): objects.c:1052-1094 /
+ * 1209-1251.  The operands' code is expanded in line (calls spill: level-1 operands as real calls cost 69.4 vs 57.4 ms on c2),
+ * and how often decides the size of the machine kernels, which do not fit the instruction cache:
+ * SPLIT: the pair node is the same in every lane (a root element tested by k_shade, every pair the lock-step machines evaluate):
+ * the operand at hand is chosen by a SCALAR index -- its node stays wave-uniform, i.e. scalar loads from the scalar cache instead of
+ * a dozen per-lane vector loads per step -- and each of the three places where the reference evaluates "one operand, then the
+ * other" (both hits, the two candidate tests, a round of the alternating walk) is a two-trip scalar loop over ONE copy of the
+ * operand code, entered by the lanes whose turn it is: two copies of operand_hit and two of operand_side per pair where
+ * round 3 had four of each, a quarter of the code two levels deep.  A lane's own sequence of evaluations, and with it every
+ * bit of its result, is the reference's. */
 template< int L, bool SPLIT, class SR, class NP, class CT > DEV double pair_hit( SR sc, NP n, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
 {
-    int want = ( n->type == ACN_PAIR_INSIDE ) ? -1 : 1;
-    int c0 = n->child0, c1 = n->child1;
-    V3 n1 = mk( 0, 0, 0 ), n2 = mk( 0, 0, 0 );
-    double a1 = operand_hit< L, SPLIT >( sc, c0, rp, rd, want_nor, &n1, cnt );
-    double a2 = operand_hit< L, SPLIT >( sc, c1, rp, rd, want_nor, &n2, cnt );
-    cnt->cost( ACN_F_PAIR_STEP );
-    if( a1 < a2 && operand_side< L >( sc, c1, ray_pos( rp, rd, a1 ), cnt ) == want ) { *nor = n1; return a1; }
-    if( a2 >= F3_INF ) return F3_INF;
-    cnt->cost( ACN_F_PAIR_STEP );
-    if( operand_side< L >( sc, c0, ray_pos( rp, rd, a2 ), cnt ) == want ) { *nor = n2; return a2; }
-    double offs = a2;
-    bool swapped = false;
-    for( ;; )
+    const int want = ( n->type == ACN_PAIR_INSIDE ) ? -1 : 1;
+    const int c0 = n->child0, c1 = n->child1;
+    if constexpr( SPLIT )
     {
-        V3 walk_p = ray_pos( rp, rd, offs );
-        double a;
-        int sd;
-        if constexpr( SPLIT )
+        V3 n1 = mk( 0, 0, 0 ), n2 = mk( 0, 0, 0 );
+        double a1 = F3_INF, a2 = F3_INF;
+        #pragma unroll 1
+        for( int k = 0; k < 2; k++ )
         {
-            if( swapped ) { a = operand_hit< L, SPLIT >( sc, c1, walk_p, rd, want_nor, &n1, cnt ); sd = a < F3_INF ? operand_side< L >( sc, c0, ray_pos( walk_p, rd, a ), cnt ) : 0; }
-            else          { a = operand_hit< L, SPLIT >( sc, c0, walk_p, rd, want_nor, &n1, cnt ); sd = a < F3_INF ? operand_side< L >( sc, c1, ray_pos( walk_p, rd, a ), cnt ) : 0; }
+            V3 nn = mk( 0, 0, 0 );
+            const double aa = operand_hit< L, SPLIT >( sc, k ? c1 : c0, rp, rd, want_nor, &nn, cnt );
+            if( k ) { a2 = aa; n2 = nn; } else { a1 = aa; n1 = nn; }
+        }
+        /* the two candidates: a1 if it is the nearer one and lies on the wanted side of operand 1, else a2 against operand 0 */
+        bool open = true;          /* the lane has no result yet */
+        double res = F3_INF;
+        #pragma unroll 1
+        for( int k = 0; k < 2; k++ )
+        {
+            if( k && open && a2 >= F3_INF ) open = false;   /* res = f3_inf */
+            const bool m = k ? open : a1 < a2;
+            if( m )
+            {
+                cnt->cost( ACN_F_PAIR_STEP );
+                const double ac = k ? a2 : a1;
+                if( operand_side< L >( sc, k ? c0 : c1, ray_pos( rp, rd, ac ), cnt ) == want ) { open = false; res = ac; if( want_nor ) *nor = k ? n2 : n1; }
+            }
+            else if( !k ) cnt->cost( ACN_F_PAIR_STEP );
+        }
+        if( !open ) return res;
+        /* the alternating walk: operand 0 from the far candidate on, then operand 1, ... until a hit lies on the wanted side of
+         * the other operand.  A round of the wave serves the lanes whose turn is operand 0, then those whose turn is operand 1 */
+        double offs = a2;
+        bool swapped = false;
+        for( ;; )
+        {
+            const V3 walk_p = ray_pos( rp, rd, offs );
+            double a = F3_INF;
+            int sd = 0;
+            #pragma unroll 1
+            for( int k = 0; k < 2; k++ )
+            {
+                if( swapped == ( k != 0 ) )
+                {
+                    a = operand_hit< L, SPLIT >( sc, k ? c1 : c0, walk_p, rd, want_nor, &n1, cnt );
+                    if( a < F3_INF ) sd = operand_side< L >( sc, k ? c0 : c1, ray_pos( walk_p, rd, a ), cnt );
+                }
+            }
             cnt->cost( ACN_F_PAIR_STEP );
             if( a >= F3_INF ) return F3_INF;
+            if( sd == want ) { if( want_nor ) *nor = n1; return offs + a; }
+            offs += a + 2 * F3_EPS;
+            if( !( offs < F3_INF ) ) return F3_INF;
+            swapped = !swapped;
         }
-        else
+    }
+    else
+    {
+        V3 n1 = mk( 0, 0, 0 ), n2 = mk( 0, 0, 0 );
+        double a1 = operand_hit< L, SPLIT >( sc, c0, rp, rd, want_nor, &n1, cnt );
+        double a2 = operand_hit< L, SPLIT >( sc, c1, rp, rd, want_nor, &n2, cnt );
+        cnt->cost( ACN_F_PAIR_STEP );
+        if( a1 < a2 && operand_side< L >( sc, c1, ray_pos( rp, rd, a1 ), cnt ) == want ) { *nor = n1; return a1; }
+        if( a2 >= F3_INF ) return F3_INF;
+        cnt->cost( ACN_F_PAIR_STEP );
+        if( operand_side< L >( sc, c0, ray_pos( rp, rd, a2 ), cnt ) == want ) { *nor = n2; return a2; }
+        double offs = a2;
+        bool swapped = false;
+        for( ;; )
         {
-            a = operand_hit< L, SPLIT >( sc, swapped ? c1 : c0, walk_p, rd, want_nor, &n1, cnt );
+            V3 walk_p = ray_pos( rp, rd, offs );
+            double a = operand_hit< L, SPLIT >( sc, swapped ? c1 : c0, walk_p, rd, want_nor, &n1, cnt );
             cnt->cost( ACN_F_PAIR_STEP );
             if( a >= F3_INF ) return F3_INF;
-            sd = operand_side< L >( sc, swapped ? c0 : c1, ray_pos( walk_p, rd, a ), cnt );
+            int sd = operand_side< L >( sc, swapped ? c0 : c1, ray_pos( walk_p, rd, a ), cnt );
+            if( sd == want ) { *nor = n1; return offs + a; }
+            offs += a + 2 * F3_EPS;
+            if( !( offs < F3_INF ) ) return F3_INF;
+            swapped = !swapped;
         }
-        if( sd == want ) { *nor = n1; return offs + a; }
-        offs += a + 2 * F3_EPS;
-        if( !( offs < F3_INF ) ) return F3_INF;
-        swapped = !swapped;
     }
 }
 
@@ -1824,16 +1898,20 @@ DEV double scene_trans_hit_dev( const SC& sc, V3 rp, V3 rd, Trans* trans, CT* cn
     Trans trans_l;
     trans_l.exit_nor = mk( 0, 0, 0 ); trans_l.exit_obj = -1; trans_l.enter_obj = -1;
     ACN_LAP( PH_FETCH );
-    if( ( a = root_trans_hit( sc, sc.light_root, rp, rd, &trans_l, cnt ) ) < min_a )
+    /* lights, then matter, through ONE in-line copy of the root traversal (and of the CSG machines in it): the root is a scalar */
+#ifdef ACN_ROOT_TWO_COPIES
+    #pragma unroll
+#else
+    #pragma unroll 1
+#endif
+    for( int k = 0; k < 2; k++ )
     {
-        min_a = a;
-        *trans = trans_l;
-    }
-    ACN_LAP( PH_LIGHT );
-    if( ( a = root_trans_hit( sc, sc.matter_root, rp, rd, &trans_l, cnt ) ) < min_a )
-    {
-        min_a = a;
-        *trans = trans_l;
+        if( ( a = root_trans_hit( sc, k ? sc.matter_root : sc.light_root, rp, rd, &trans_l, cnt ) ) < min_a )
+        {
+            min_a = a;
+            *trans = trans_l;
+        }
+        if( k == 0 ) ACN_LAP( PH_LIGHT );
     }
     ACN_LAP( PH_ROOT_LEAF );
     return min_a;

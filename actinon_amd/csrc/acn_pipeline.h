@@ -813,6 +813,24 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
         double intensity = 1.0;
         int depth = ( int )sc.prm.trace_depth;
         if( src && live ) { T = src->T; intensity = src->intensity; depth = src->depth; pixel = src->pixel; }
+#ifdef ACN_WALK_REFETCH
+        /* ... and origin and direction are read (camera rays: computed) a second time for the shading: twelve registers less
+         * across the traversal, which copies them anyway */
+        if( src ) { if( live ) { rp = src->p; rd = src->d; } }
+        else
+        {
+            asm volatile( "" : "+v"( pixel ) );
+            double mx, my;
+            if( pos_xy ) { mx = pos_xy[ ( size_t )pixel * 2 ]; my = pos_xy[ ( size_t )pixel * 2 + 1 ]; }
+            else
+            {
+                size_t pix = first_pixel + pixel;
+                mx = ( double )( pix % sc.prm.image_width ) + 0.5;
+                my = ( double )( pix / sc.prm.image_width ) + 0.5;
+            }
+            camera_ray( sc, mx, my, &rp, &rd );
+        }
+#endif
         bool hit = live && offs < F3_INF;
         V3 acc = mk( 0, 0, 0 );
         if( live && !hit ) acc = v_mld( T, v_mlf( ld3( sc.prm.background_color ), intensity ) );

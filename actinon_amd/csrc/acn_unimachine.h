@@ -92,16 +92,15 @@ DEV_SIDE int obj_side_uni( SR sc, int root, bool act, V3 pos, CT* cnt )
                 else                            { r = distance_side( n, pos ); cnt->inc( CNT_SDF_EVAL ); }
             }
         }
-#if ACN_UNI_PAIR_LEVEL >= 1
+#if ACN_UNI_PAIR_LEVEL >= 2
+        else if( nflags & ( ACN_GFLAG_LEAF_PAIR | ACN_GFLAG_PAIR2 ) )
+        {
+            if( in ) r = pair_side< 2 >( g, n, pos, cnt );   /* (leaf pairs too: one expansion of the pair code) */
+        }
+#elif ACN_UNI_PAIR_LEVEL >= 1
         else if( nflags & ACN_GFLAG_LEAF_PAIR )
         {
             if( in ) r = pair_side< 1 >( g, n, pos, cnt );
-        }
-#endif
-#if ACN_UNI_PAIR_LEVEL >= 2
-        else if( nflags & ACN_GFLAG_PAIR2 )
-        {
-            if( in ) r = pair_side< 2 >( g, n, pos, cnt );
         }
 #endif
         else if( depth >= ACN_CSG_MAX_DEPTH )
@@ -230,8 +229,9 @@ DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp, V3 rd, V3* out_nor, CT* 
             if( in )
             {
 #if ACN_UNI_PAIR_LEVEL >= 2
-                ret_a = ( nflags & ACN_GFLAG_PAIR2 ) ? pair_hit< 2, true >( g, n, rp, rd, NOR, &ret_n, cnt )
-                                                     : pair_hit< 1, true >( g, n, rp, rd, NOR, &ret_n, cnt );
+                /* (a leaf pair through the level-2 code as well: its operands are simple, so every step is the level-1 step,
+                 * and the kernel carries one expansion of the pair code instead of two) */
+                ret_a = pair_hit< 2, true >( g, n, rp, rd, NOR, &ret_n, cnt );
 #else
                 ret_a = pair_hit< 1, true >( g, n, rp, rd, NOR, &ret_n, cnt );
 #endif
