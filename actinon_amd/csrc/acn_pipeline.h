@@ -196,7 +196,14 @@ typedef ChunkState ACN_LDS* ChunkP;
 #define ACN_NCHUNKS 8     /* reservation states per wave */
 /* LDS block of the reservation states of a 256-lane workgroup; 256 B keeps the dynamic LDS behind it 16-byte aligned */
 #define ACN_CHUNK_STATES __shared__ __attribute__( ( aligned( 16 ) ) ) ChunkState acn_chunk_states[ 4 * ACN_NCHUNKS ];
-#define ACN_CHUNKS_OF_WAVE ( ( ChunkP )acn_chunk_states + ( threadIdx.x >> 6 ) * ACN_NCHUNKS )
+/* (the wave's index through readfirstlane: the pointer is then a scalar.  As a per-lane value derived from threadIdx.x it was
+ * spilled and re-loaded from scratch four times per append: ~80 of the ~110 scratch loads of a k_walk step, profiles/r04) */
+#define ACN_CHUNKS_OF_WAVE ( ( ChunkP )acn_chunk_states + __builtin_amdgcn_readfirstlane( ( int )( threadIdx.x >> 6 ) ) * ACN_NCHUNKS )
+/* how many lanes of `mask` lie below the calling lane: two VALU instructions, no lane index or lane mask kept in registers */
+DEV uint32_t lanes_below( unsigned long long mask )
+{
+    return __builtin_amdgcn_mbcnt_hi( ( uint32_t )( mask >> 32 ), __builtin_amdgcn_mbcnt_lo( ( uint32_t )mask, 0u ) );
+}
 
 DEV void chunks_init( ChunkP cs )
 {
@@ -233,11 +240,11 @@ DEV uint32_t chunk_alloc( ChunkP cs, uint32_t* counter, bool want )
 {
     unsigned long long mask = __ballot( want );
     if( !want ) return ACN_INVALID;
-    int lane = ( int )( threadIdx.x & 63 );
-    int leader = __builtin_amdgcn_readfirstlane( __ffsll( ( long long )mask ) - 1 );
+    /* from here on the active lanes are those with `want`: the first of them (rank 0) leads, and readfirstlane reads it */
+    const uint32_t rank = lanes_below( mask );
     uint32_t m = ( uint32_t )__popcll( mask );
     uint32_t base = 0, room = 0, base2 = 0;
-    if( lane == leader )
+    if( rank == 0 )
     {
         uint32_t cur = cs->cur, end = cs->end;
         base = cur; room = end - cur;
@@ -251,10 +258,9 @@ DEV uint32_t chunk_alloc( ChunkP cs, uint32_t* counter, bool want )
         }
         else cs->cur = cur + m;
     }
-    base  = ( uint32_t )__builtin_amdgcn_readlane( ( int )base, leader );
-    room  = ( uint32_t )__builtin_amdgcn_readlane( ( int )room, leader );
-    base2 = ( uint32_t )__builtin_amdgcn_readlane( ( int )base2, leader );
-    uint32_t rank = ( uint32_t )__popcll( mask & ( ( 1ull << lane ) - 1ull ) );
+    base  = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )base );
+    room  = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )room );
+    base2 = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )base2 );
     return rank < room ? base + rank : base2 + ( rank - room );
 }
 
@@ -272,12 +278,11 @@ DEV uint32_t wave_alloc( uint32_t* counter, bool want )
 {
     unsigned long long mask = __ballot( want );
     if( !want ) return ACN_INVALID;
-    int lane = ( int )( threadIdx.x & 63 );
-    int leader = __builtin_amdgcn_readfirstlane( __ffsll( ( long long )mask ) - 1 );
+    const uint32_t rank = lanes_below( mask );
     uint32_t base = 0;
-    if( lane == leader ) base = atomicAdd( counter, ( uint32_t )__popcll( mask ) );
-    base = ( uint32_t )__builtin_amdgcn_readlane( ( int )base, leader );
-    return base + ( uint32_t )__popcll( mask & ( ( 1ull << lane ) - 1ull ) );
+    if( rank == 0 ) base = atomicAdd( counter, ( uint32_t )__popcll( mask ) );
+    base = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )base );
+    return base + rank;
 }
 
 DEV void wave_stat_add( uint32_t* counter, uint32_t v )   /* all lanes of the wave */
@@ -404,7 +409,7 @@ struct WalkSink
     {
         if( !priv ) { out.push( want, p, d, T, intensity, depth, pixel ); return; }
         unsigned long long mask = __ballot( want );
-        uint32_t slot = top + ( uint32_t )__popcll( mask & ( ( 1ull << ( threadIdx.x & 63 ) ) - 1ull ) );
+        uint32_t slot = top + lanes_below( mask );
         uint32_t new_top = top + ( uint32_t )__popcll( mask );
         bool fits = slot < cap;
         if( want && fits )
@@ -434,7 +439,7 @@ DEV void probe_push( const TaskQ& tq, ChunkP pcs, bool want, V3 p, V3 d, double 
     {
         /* statistics: one add per wave and call */
         const unsigned long long m = __ballot( 1 );
-        if( ( int )( threadIdx.x & 63 ) == __ffsll( ( long long )m ) - 1 ) atomicAdd( &tq.counts[ QS_PROBES ], ( uint32_t )__popcll( m ) );
+        if( lanes_below( m ) == 0 ) atomicAdd( &tq.counts[ QS_PROBES ], ( uint32_t )__popcll( m ) );
         if( slot < tq.probe_cap )
         {
             HardShadow& h = tq.probes[ slot ];
@@ -695,8 +700,10 @@ struct TileOrder
     uint32_t n;         /* positions of the call */
     uint32_t n_tiles;   /* ceil( n / 256 ) */
     uint32_t mul;
+    uint32_t sample_stride;   /* > 0: the learning pass of a cold handle (learn_rates): slot s stands for position s * sample_stride */
     DEV uint32_t position( uint32_t slot ) const
     {
+        if( sample_stride ) { const uint64_t p = ( uint64_t )slot * sample_stride; return p < n ? ( uint32_t )p : 0xFFFFFFFFu; }
         uint32_t tile = ( uint32_t )( ( ( uint64_t )( slot >> ACN_ORDER_SHIFT ) * mul ) % n_tiles );
         return ( tile << ACN_ORDER_SHIFT ) + ( slot & ( ( 1u << ACN_ORDER_SHIFT ) - 1u ) );
     }

@@ -95,6 +95,7 @@ struct Tunables
                                         * last chunk (learned_grid); 2 only launches whose input was empty then get a small grid.  Measured, off: see learned_grid */
     double   grid_passes = 1.0;        /* ACN_GRID_PASSES: a learned grid gives a workgroup this many workgroup-loads of the input it expects (x 1/2: head room) */
     bool     learn_passes = true;      /* ACN_LEARN_PASSES=0: every level gets ACN_WALK_PASSES launches of k_walk, needed or not */
+    bool     learn_sample = true;      /* ACN_LEARN_SAMPLE=0: no strided learning pass on a cold handle (learn_rates): the first chunks learn, as in round 3 */
     bool     count_work = false;       /* ACN_COUNT_WORK */
     bool     stage_timing = false;     /* ACN_STAGE_TIMING */
     void read()
@@ -121,6 +122,7 @@ struct Tunables
         count_work = getenv( "ACN_COUNT_WORK" ) != nullptr;
         if( const char* e = getenv( "ACN_LEARN_PASSES" ) ) learn_passes = atoi( e ) != 0;
         if( const char* e = getenv( "ACN_LEARN_GRIDS" ) ) learn_grids = atoi( e );
+        if( const char* e = getenv( "ACN_LEARN_SAMPLE" ) ) learn_sample = atoi( e ) != 0;
         if( const char* e = getenv( "ACN_WS_UNIFORM" ) ) ws_uniform = atoi( e ) != 0;
         debug_chunks = getenv( "ACN_DEBUG_CHUNKS" ) != nullptr;
         if( const char* e = getenv( "ACN_GRID_PASSES" ) ) { grid_passes = atof( e ); if( !( grid_passes >= 0.25 && grid_passes <= 64.0 ) ) grid_passes = 1.0; }
@@ -1241,6 +1243,73 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
     return ACN_OK;
 }
 
+/* the rates of a handle from the queue marks of one chunk of cnt positions */
+static void set_rates( acn_scene_handle* h, uint32_t cnt, const uint32_t* fill, double dead_share )
+{
+    /* (a chunk of a few positions: mostly dead slots, 64 positions of hanging_lamp p1024 mark 15 600 deferred rays per position
+     * where 3 500 is the rate -- the counted share of the deferred-shadow queue corrects all five) */
+    const double live = cnt <= 4096 && dead_share > 0 && dead_share < 0.95 ? 1.0 - dead_share : 1.0;
+    for( int q = 0; q < WQ_N; q++ ) h->rate[ q ] = f_max_host( live * ( double )fill[ q ] / ( double )cnt, 1e-3 );
+    h->rate_cnt = cnt;
+}
+
+/* Cold handle: the queue demand per position is learned from a SAMPLE of the call's own positions -- every ( n / m )-th of them,
+ * m = 512 .. 4096 -- rendered once on the starter queues and thrown away, before anything is sized.  Round 3 let the first
+ * chunks of the call learn: the first tile of the order is a corner of the picture (C4: 1 shading task and 161 deferred path rays
+ * per position where the frame's average is 300 / 1 800), so the queues were found one by one by halving -- 12 redone chunks on
+ * the C3 / C4 frames, a first frame of 718 ms on paraffin_lamp where the second takes 465 -- and every lane of a call learned
+ * for itself and re-sized its queues in the middle of the frame.  A sample over the whole frame costs one short chain of
+ * launches (a few ms; nothing next to a frame whose queues must be allocated anyway) and is trusted like a large chunk: the
+ * queues are then sized ONCE, while the device is idle (launch_render; render_lanes for all lanes of a call). */
+static int learn_rates( acn_scene_handle* h, const double* d_pos_xy, size_t first, size_t n, hipStream_t stream )
+{
+    if( rates_known( h ) || !h->tun.learn_sample || h->tun.chunk || h->tun.ws_uniform || n < 16384 ) return ACN_OK;
+    int st = ensure_workspace( h, 4096 );   /* the starter set */
+    if( st != ACN_OK ) return st;
+    if( h->accum_cap < n )
+    {
+        if( h->d_accum ) hipFree( h->d_accum );
+        h->d_accum = nullptr; h->accum_cap = 0;
+        HIP_TRY( hipMalloc( &h->d_accum, sizeof( unsigned long long ) * 3 * n ) );
+        h->accum_cap = n;
+    }
+    /* as many positions as the starter queues hold by the guess launch_render makes for a first chunk, 4096 at most */
+    const size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
+    size_t want = ( size_t )( ( double )h->ws.cap[ WQ_CHILDREN ] / ( ( double )( s + 2 ) * ( s > 64 ? ( double )s / 64.0 : 1.0 ) ) );
+    const size_t by_shadow = ( size_t )( ( double )h->ws.cap[ WQ_HARD_SHADOW ] / ( 0.25 * ( double )( h->dev.prm.direct_samples * h->n_lights + s ) + 4.0 ) );
+    if( want > by_shadow ) want = by_shadow;
+    if( want > 4096 ) want = 4096;
+    if( want > n / 4 ) want = n / 4;
+    const bool count_work = h->count_work, stage_timing = h->stage_timing;
+    h->count_work = false; h->stage_timing = false; h->shard_rank = 0; h->shard_world = 1;
+    h->events_used = 0;
+    for( ; want >= 64; want /= 2 )
+    {
+        TileOrder order;
+        order.n = ( uint32_t )n; order.n_tiles = 1; order.mul = 1;
+        order.sample_stride = ( uint32_t )( n / want );
+        const uint32_t cnt = ( uint32_t )want;
+        hipLaunchKernelGGL( k_clear_slots, dim3( ( cnt + 255 ) / 256 ), dim3( 256 ), 0, stream, h->d_accum, 0u, cnt, order );
+        HIP_TRY( hipGetLastError() );
+        int overflow = 0;
+        uint32_t fill[ WQ_N ];
+        double dead_share = 0;
+        st = render_chunk( h, d_pos_xy, first, 0u, cnt, order, stream, &overflow, fill, &dead_share );
+        if( st != ACN_OK ) break;
+        if( h->tun.debug_chunks )
+            fprintf( stderr, "[acn sample] %u positions (every %u-th) %s dead %.2f | per pos T %.1f C %.1f HS %.1f HP %.1f R %.1f\n", cnt, order.sample_stride, overflow ? "OVERFLOW" : "ok",
+                     dead_share, fill[ 0 ] / ( double )cnt, fill[ 1 ] / ( double )cnt, fill[ 2 ] / ( double )cnt, fill[ 3 ] / ( double )cnt, fill[ 4 ] / ( double )cnt );
+        if( overflow ) continue;
+        set_rates( h, cnt, fill, dead_share );
+        h->rate_cnt = 8192;   /* a sample of the whole frame: trusted like a chunk that size (launch_render re-sizes for the whole rest at once) */
+        break;
+    }
+    for( int level = 0; level <= ACN_MAX_PATH_LEVELS; level++ ) h->walk_passes_seen[ level ] = 0;
+    h->seen_cnt = 0;
+    h->count_work = count_work; h->stage_timing = stage_timing;
+    return st;
+}
+
 static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t first, size_t n, double* d_out_rgb,
                           const acn_render_opts* opts, hipStream_t stream )
 {
@@ -1257,7 +1326,11 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     }
     else if( opts && opts->shard_mode > ACN_SHARD_SAMPLES ) return fail( ACN_ERR_ARG, "unknown shard_mode" );
     h->stage_timing = ( opts && ( opts->flags & ACN_OPT_STAGE_TIMING ) ) || h->tun.stage_timing;
-    int st = ensure_workspace( h, n );
+    int st = learn_rates( h, d_pos_xy, first, n, stream );
+    if( st != ACN_OK ) return st;
+    /* (shard fields again: the learning pass renders unsharded) */
+    if( opts && opts->shard_mode == ACN_SHARD_SAMPLES && opts->shard_world > 1 ) { h->shard_rank = opts->shard_rank; h->shard_world = opts->shard_world; }
+    st = ensure_workspace( h, n );
     if( st != ACN_OK ) return st;
     if( h->accum_cap < n )
     {
@@ -1301,6 +1374,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     order.n = ( uint32_t )n;
     order.n_tiles = ( uint32_t )( ( n + ( ( 1u << ACN_ORDER_SHIFT ) - 1 ) ) >> ACN_ORDER_SHIFT );
     order.mul = 1;
+    order.sample_stride = 0;
     if( order.n_tiles > 2 )
     {
         auto gcd = []( uint64_t a, uint64_t b ) { while( b ) { uint64_t t = a % b; a = b; b = t; } return a; };
@@ -1353,14 +1427,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
          * waves' queue reservations do not scale with the chunk, so small chunks over-estimate); otherwise the rates
          * follow upwards at once and forget slowly. */
         const bool known = rates_known( h );
-        if( !known || cnt >= 4 * h->rate_cnt )
-        {
-            /* (a first chunk of a few positions: mostly dead slots, 64 positions of hanging_lamp p1024 mark 15 600 deferred
-             * rays per position where 3 500 is the rate -- the counted share of the deferred-shadow queue corrects all five) */
-            const double live = cnt < 4096 && dead_share > 0 && dead_share < 0.95 ? 1.0 - dead_share : 1.0;
-            for( int q = 0; q < WQ_N; q++ ) h->rate[ q ] = f_max_host( live * ( double )fill[ q ] / ( double )cnt, 1e-3 );
-            h->rate_cnt = cnt;
-        }
+        if( !known || cnt >= 4 * h->rate_cnt ) set_rates( h, cnt, fill, dead_share );
         else
         {
             /* (also after small chunks: where chunks are small the demand per position is large and the dead slots do not
@@ -1500,6 +1567,25 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
     /* what the caller queued on `stream` before this call must be done before the lanes read the positions */
     HIP_TRY( hipEventRecord( h->ev0, stream ) );
     HIP_TRY( hipEventSynchronize( h->ev0 ) );
+    /* a cold handle learns the scene's queue demand once, for all lanes, from a sample of the call (learn_rates) */
+    if( !rates_known( h->lanes[ 0 ] ) )
+    {
+        h->budget_div = 1;
+        int st = learn_rates( h, d_pos_xy, first, n, stream );
+        if( st != ACN_OK ) return st;
+        HIP_TRY( hipStreamSynchronize( stream ) );
+        if( rates_known( h ) )
+        {
+            for( int k = 0; k < lanes; k++ )
+            {
+                acn_scene_handle* l = h->lanes[ k ];
+                if( rates_known( l ) ) continue;
+                for( int q = 0; q < WQ_N; q++ ) l->rate[ q ] = h->rate[ q ];
+                l->rate_cnt = h->rate_cnt; l->ctl.fill_target = h->ctl.fill_target;
+            }
+            free_workspace( h );   /* the bound is the handle's, whoever uses it */
+        }
+    }
     /* The lanes' queues are (re-)sized here, while the device is idle: hipFree synchronises the device, so lanes that
      * re-size at the start of their chains wait for each other's chunks (second frame of paraffin_lamp 400x600, whose
      * queues are trimmed to the rates the first frame learned: 2.1 s instead of 0.45, profiles/r03/frames_paraffin_*.txt) */

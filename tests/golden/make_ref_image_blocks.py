@@ -45,6 +45,16 @@ def main():
     with open(OUT, "w") as f:
         json.dump(out, f)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
+    # 8 x 8 blocks (edge blocks included: 400 / 8 = 50 exactly) of the two pictures the tight pin uses
+    # (tests/test_reference_images.py::test_oracle_with_gradient_cycles_matches_shipped_render)
+    out8 = {"block": 8, "unit": out["unit"], "source": out["source"], "images": {}}
+    for name in ("primitives", "wine_glass"):
+        img = np.asarray(Image.open(os.path.join(REF, IMAGES[name])).convert("RGB"))
+        out8["images"][name] = {"file": IMAGES[name], "width": int(img.shape[1]), "height": int(img.shape[0]),
+                                "block_means": np.round(block_means(img, 8), 3).tolist()}
+    with open(OUT.replace("blocks.json", "blocks8.json"), "w") as f:
+        json.dump(out8, f)
+    print("wrote", OUT.replace("blocks.json", "blocks8.json"))
 
 
 if __name__ == "__main__":
