@@ -53,10 +53,11 @@ void acn_launch_shade_hits( bool count, const LevelQ& q, hipStream_t stream, con
                             unsigned long long* accum, unsigned long long* counters );
 void acn_launch_shade( int cls, KernelFlags f, const LevelQ& q, hipStream_t stream, const SceneArgs& s,
                        unsigned long long* accum, unsigned long long* counters );
-void acn_launch_shade64( KernelFlags, const LevelQ&, hipStream_t, const SceneArgs&, unsigned long long*, unsigned long long* );
-void acn_launch_shade16( KernelFlags, const LevelQ&, hipStream_t, const SceneArgs&, unsigned long long*, unsigned long long* );
-void acn_launch_shade4( KernelFlags, const LevelQ&, hipStream_t, const SceneArgs&, unsigned long long*, unsigned long long* );
-void acn_launch_shade1( KernelFlags, const LevelQ&, hipStream_t, const SceneArgs&, unsigned long long*, unsigned long long* );
+/* part: ACN_SHADE_BOTH, or one half of a fissioned launch (ACN_SHADE_DIRECT / ACN_SHADE_PATH) */
+void acn_launch_shade64( KernelFlags, const LevelQ&, hipStream_t, const SceneArgs&, unsigned long long*, unsigned long long*, int part );
+void acn_launch_shade16( KernelFlags, const LevelQ&, hipStream_t, const SceneArgs&, unsigned long long*, unsigned long long*, int part );
+void acn_launch_shade4( KernelFlags, const LevelQ&, hipStream_t, const SceneArgs&, unsigned long long*, unsigned long long*, int part );
+void acn_launch_shade1( KernelFlags, const LevelQ&, hipStream_t, const SceneArgs&, unsigned long long*, unsigned long long*, int part );
 void acn_launch_hard_shadow( KernelFlags f, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
                              unsigned long long* accum, unsigned long long* counters );
 void acn_launch_hard_path( KernelFlags f, const LevelQ& q, size_t lds_bytes, hipStream_t stream, const SceneArgs& s,
@@ -74,14 +75,20 @@ void acn_launch_hard_path( KernelFlags f, const LevelQ& q, size_t lds_bytes, hip
 
 /* body of acn_launch_shade<LPT>: shared by the four k_shade translation units */
 #define ACN_DEFINE_LAUNCH_SHADE( NAME, LPT, CLS ) \
-void NAME( KernelFlags f, const LevelQ& q, hipStream_t stream, const SceneArgs& s, unsigned long long* accum, unsigned long long* counters ) \
+template< int PART > static void NAME##_part( KernelFlags f, const LevelQ& q, hipStream_t stream, const SceneArgs& s, unsigned long long* accum, unsigned long long* counters ) \
 { \
-    if( f.count && f.prune ) { if( f.leaf_lights ) ACN_LS_( LPT, CLS, true, true, true );  else ACN_LS_( LPT, CLS, true, false, true ); } \
-    else if( f.count ) { if( f.leaf_lights ) ACN_LS_( LPT, CLS, true, true, false );  else ACN_LS_( LPT, CLS, true, false, false ); } \
-    else if( f.prune ) { if( f.leaf_lights ) ACN_LS_( LPT, CLS, false, true, true );  else ACN_LS_( LPT, CLS, false, false, true ); } \
-    else               { if( f.leaf_lights ) ACN_LS_( LPT, CLS, false, true, false ); else ACN_LS_( LPT, CLS, false, false, false ); } \
+    if( f.count && f.prune ) { if( f.leaf_lights ) ACN_LS_( LPT, CLS, true, true, true, PART );  else ACN_LS_( LPT, CLS, true, false, true, PART ); } \
+    else if( f.count ) { if( f.leaf_lights ) ACN_LS_( LPT, CLS, true, true, false, PART );  else ACN_LS_( LPT, CLS, true, false, false, PART ); } \
+    else if( f.prune ) { if( f.leaf_lights ) ACN_LS_( LPT, CLS, false, true, true, PART );  else ACN_LS_( LPT, CLS, false, false, true, PART ); } \
+    else               { if( f.leaf_lights ) ACN_LS_( LPT, CLS, false, true, false, PART ); else ACN_LS_( LPT, CLS, false, false, false, PART ); } \
+} \
+void NAME( KernelFlags f, const LevelQ& q, hipStream_t stream, const SceneArgs& s, unsigned long long* accum, unsigned long long* counters, int part ) \
+{ \
+    if( part == ACN_SHADE_DIRECT )    NAME##_part< ACN_SHADE_DIRECT >( f, q, stream, s, accum, counters ); \
+    else if( part == ACN_SHADE_PATH ) NAME##_part< ACN_SHADE_PATH >( f, q, stream, s, accum, counters ); \
+    else                              NAME##_part< ACN_SHADE_BOTH >( f, q, stream, s, accum, counters ); \
 }
-#define ACN_LS_( LPT, CLS, C, L, P ) hipLaunchKernelGGL( ( k_shade< LPT, C, L, P > ), dim3( q.shade_grid ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS_OF( s ), \
+#define ACN_LS_( LPT, CLS, C, L, P, PART ) hipLaunchKernelGGL( ( k_shade< LPT, C, L, P, PART > ), dim3( q.shade_grid ), dim3( 256 ), 0, stream, ACN_SCENE_ARGS_OF( s ), \
     ( const DTask* )q.tasks, ( const uint32_t* )q.idx[ CLS ], CLS, q.task_cap, q.fetch_shade * ( 64u / LPT ), q.children, q.child_cap, q.hard_shadow, q.hard_path, q.hs_cap, q.hard_cap, q.counts, q.shard_rank, q.shard_world, accum, counters )
 
 #endif

@@ -163,6 +163,12 @@ enum
 {
     QC_TASKS = 0, QC_CLASS0 = 1, QC_CHILDREN = 5, QC_FLAGS = 6, QC_HARD_SHADOW = 7, QC_HARD_PATH = 8,
     QC_CUR_HS = 9, QC_CUR_HP = 10, QC_CUR_HITS = 11, QC_CUR_SHADE0 = 20,   /* .. QC_CUR_SHADE0 + 3: one per size class */
+    QC_CUR_SHADEP0 = 24,   /* .. + 3: the same for the path half of a fissioned k_shade (ACN_SHADE_PATH), which walks the same task lists */
+    /* reserved slots no record was written to (the unused ends of the waves' reservations): mark - dead = records, exactly.
+     * Tasks, path-sample hits, deferred path rays, specular rays (all generations of the level together); the deferred-shadow
+     * queue has QS_HARD_SHADOW + QS_PROBES.  The dead slots of a chunk do not scale with it -- ~64 per wave, queue and launch --
+     * so the marks of a SMALL chunk overstate its demand several times (learn_rates) */
+    QS_DEAD_T = 28, QS_DEAD_C = 29, QS_DEAD_HP = 30, QS_DEAD_R = 31,
     QS_WALK_RAYS = 12, QS_HARD_SHADOW = 13, QS_HARD_PATH = 14, QS_CHILDREN = 15, QS_TASKS = 16, QS_WALK_STEPS = 17, QS_PRIVATE_RAYS = 18,
     QS_PROBES = 19,   /* specular rays that were answered by an any-hit probe instead of a walk (probe_push) */
     QC_GEN = 32, QC_CUR_GEN = QC_GEN + ACN_MAX_WALK_PASSES + 1,
@@ -266,11 +272,13 @@ DEV uint32_t chunk_alloc( ChunkP cs, uint32_t* counter, bool want )
 
 /* end of a kernel (all lanes of the wave): the unused tail of the wave's last reservation is dead */
 template< class KILL >
-DEV void chunk_close( ChunkP cs, uint32_t cap, KILL kill )
+DEV void chunk_close( ChunkP cs, uint32_t cap, KILL kill, uint32_t* dead = nullptr )
 {
     uint32_t cur = cs->cur, end = cs->end, spare = cs->spare;
     for( uint32_t k = cur + ( threadIdx.x & 63 ); k < end; k += 64 ) if( k < cap ) kill( k );
     if( spare != ACN_INVALID_SLOT ) for( uint32_t k = spare + ( threadIdx.x & 63 ); k < spare + ACN_QCHUNK; k += 64 ) if( k < cap ) kill( k );
+    const uint32_t d = end - cur + ( spare != ACN_INVALID_SLOT ? ( uint32_t )ACN_QCHUNK : 0u );
+    if( dead && d && ( threadIdx.x & 63 ) == 0 ) atomicAdd( dead, d );
 }
 
 /* one atomic per wave: every lane with `want` gets a distinct slot (unreserved form, used where appends are rare) */
@@ -384,10 +392,10 @@ struct RayQ
             else atomicOr( flags, ACN_FLAG_CHILD_OVERFLOW );
         }
     }
-    DEV void close() const
+    DEV void close( uint32_t* dead ) const
     {
         RayTask* r = rays;
-        chunk_close( cs, cap, [ r ]( uint32_t k ) { r[ k ].pixel = ACN_INVALID; } );
+        chunk_close( cs, cap, [ r ]( uint32_t k ) { r[ k ].pixel = ACN_INVALID; }, dead );
     }
 };
 
@@ -603,6 +611,8 @@ DEV void shade_hit( const DevScene& sc, RAYS& rays, const TaskQ& tq, ChunkP tcs,
 /* the index lists' reservations of a wave end with the kernel, and that of its probes */
 DEV void task_chunks_close( const TaskQ& tq, ChunkP tcs )
 {
+    /* (task slots need no dead marks -- tasks are reached through the index lists -- but the end of the wave's reservation counts) */
+    chunk_close( tcs, 0u, []( uint32_t ) {}, &tq.counts[ QS_DEAD_T ] );
     {
         HardShadow* pr = tq.probes;
         chunk_close( tcs + 6, tq.probe_cap, [ pr ]( uint32_t j ) { pr[ j ].pixel = ACN_INVALID; } );
@@ -854,7 +864,7 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
     ACN_PHASE_FLUSH( counters, 0 )
     /* the step bound is a safety net against a loop that does not end; work would be lost, so the call fails */
     if( !finished && lane == 0 ) atomicOr( sc_in.flags, ACN_FLAG_STACK_OVERFLOW );
-    sink.out.close();
+    sink.out.close( p_counts + QS_DEAD_R );
     task_chunks_close( tq, cs );
     wave_stat_add( p_counts + QS_WALK_RAYS, traced );
     if( sink.priv ) wave_stat_add( p_counts + QS_PRIVATE_RAYS, traced );
@@ -906,7 +916,7 @@ void k_shade_hits( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const HitRec* __restrict_
         shade_hit( sc, rq, tq, cs, r.p, r.d, r.offs, trans, live ? r.depth : 0, r.intensity, r.T, r.pixel, acc, &cnt );
         if( live ) pixel_add( accum, sc.flags, r.pixel, acc );
     }
-    rq.close();
+    rq.close( p_counts + QS_DEAD_R );
     task_chunks_close( tq, cs );
     wave_add_counters( counters, cnt );
 }
@@ -1028,7 +1038,7 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
     for( ;; )
     {
         uint32_t base = 0;
-        uint32_t got = range_take( fr, p_counts + QC_CUR_SHADE0 + cls, fetch_batch, n_tasks, ( uint32_t )G, &base );
+        uint32_t got = range_take( fr, p_counts + ( PART == ACN_SHADE_PATH ? QC_CUR_SHADEP0 : QC_CUR_SHADE0 ) + cls, fetch_batch, n_tasks, ( uint32_t )G, &base );
         if( got == 0 ) break;
         uint32_t ti = base + grp;
         if( ( uint32_t )grp >= got ) continue;
@@ -1287,8 +1297,8 @@ void k_shade( ACN_SCENE_PARAMS, const DTask* __restrict__ tasks, const uint32_t*
         ACN_LAP( PH_SHADE );
     }
     chunk_close( cs + 0, hs_cap, kill_hs );
-    chunk_close( cs + 1, hard_cap, kill_hp );
-    chunk_close( cs + 2, child_cap, kill_ch );
+    chunk_close( cs + 1, hard_cap, kill_hp, p_counts + QS_DEAD_HP );
+    chunk_close( cs + 2, child_cap, kill_ch, p_counts + QS_DEAD_C );
     wave_stat_add( p_counts + QS_HARD_SHADOW, n_hs );
     wave_stat_add( p_counts + QS_HARD_PATH, n_hp );
     wave_stat_add( p_counts + QS_CHILDREN, n_ch );
@@ -1425,7 +1435,7 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
     }
     ACN_LAP( PH_SHADE );
     ACN_PHASE_FLUSH( counters, 2 )
-    chunk_close( cs + 0, child_cap, kill_ch );
+    chunk_close( cs + 0, child_cap, kill_ch, p_counts + QS_DEAD_C );
     wave_stat_add( p_counts + QS_CHILDREN, n_ch );
     wave_add_counters( counters, cnt );
 }

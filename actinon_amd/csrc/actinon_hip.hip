@@ -95,6 +95,10 @@ struct Tunables
                                         * last chunk (learned_grid); 2 only launches whose input was empty then get a small grid.  Measured, off: see learned_grid */
     double   grid_passes = 1.0;        /* ACN_GRID_PASSES: a learned grid gives a workgroup this many workgroup-loads of the input it expects (x 1/2: head room) */
     bool     learn_passes = true;      /* ACN_LEARN_PASSES=0: every level gets ACN_WALK_PASSES launches of k_walk, needed or not */
+    bool     shade_fission = false;    /* ACN_SHADE_FISSION=1: the two sample loops of a shading point run as two launches, the direct-light half and its
+                                          deferred shadow rays on a side stream (render_chunk).  Measured and OFF: 1080p 52.0 -> 56.7 ms, the 1/8 share
+                                          13.7 -> 17 - 20 ms, c2 28.0 -> 31.9, paraffin_lamp 365 -> 400 - 450 (profiles/r04/ab_fission.txt): every lane then
+                                          has two streams of persistent grids, and eight grids of 512 - 1024 workgroups take turns on one chip */
     bool     learn_sample = true;      /* ACN_LEARN_SAMPLE=0: no strided learning pass on a cold handle (learn_rates): the first chunks learn, as in round 3 */
     bool     count_work = false;       /* ACN_COUNT_WORK */
     bool     stage_timing = false;     /* ACN_STAGE_TIMING */
@@ -123,6 +127,7 @@ struct Tunables
         if( const char* e = getenv( "ACN_LEARN_PASSES" ) ) learn_passes = atoi( e ) != 0;
         if( const char* e = getenv( "ACN_LEARN_GRIDS" ) ) learn_grids = atoi( e );
         if( const char* e = getenv( "ACN_LEARN_SAMPLE" ) ) learn_sample = atoi( e ) != 0;
+        if( const char* e = getenv( "ACN_SHADE_FISSION" ) ) shade_fission = atoi( e ) != 0;
         if( const char* e = getenv( "ACN_WS_UNIFORM" ) ) ws_uniform = atoi( e ) != 0;
         debug_chunks = getenv( "ACN_DEBUG_CHUNKS" ) != nullptr;
         if( const char* e = getenv( "ACN_GRID_PASSES" ) ) { grid_passes = atof( e ); if( !( grid_passes >= 0.25 && grid_passes <= 64.0 ) ) grid_passes = 1.0; }
@@ -165,6 +170,8 @@ struct acn_scene_handle
     acn_texture* d_textures = nullptr;
     SCEntry* d_sc_table = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;         /* the direct-light half of a fissioned level and its deferred shadow rays (render_chunk) */
+    hipEvent_t ev_fork = nullptr, ev_path = nullptr, ev_join = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int cur_stage = 0;
@@ -530,8 +537,12 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
 #define HIP_TRY_H( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) \
     return bail( fail( ACN_ERR_DEVICE, std::string( #expr ) + ": " + hipGetErrorString( e_ ) ) ); } while( 0 )
     HIP_TRY_H( hipStreamCreate( &h->stream ) );
+    HIP_TRY_H( hipStreamCreateWithFlags( &h->side_stream, hipStreamNonBlocking ) );
     HIP_TRY_H( hipEventCreate( &h->ev0 ) );
     HIP_TRY_H( hipEventCreate( &h->ev1 ) );
+    HIP_TRY_H( hipEventCreateWithFlags( &h->ev_fork, hipEventDisableTiming ) );
+    HIP_TRY_H( hipEventCreateWithFlags( &h->ev_path, hipEventDisableTiming ) );
+    HIP_TRY_H( hipEventCreateWithFlags( &h->ev_join, hipEventDisableTiming ) );
 
     /* ABI layout -> device layout: geometry (GNode) and shading properties (GMat) split */
     std::vector< GNode > nodes( scene->n_nodes );
@@ -816,6 +827,22 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
          *   stacks only      beyond (the node array stays in global memory / L2).
          * ACN_LDS_MAX (bytes of nodes that may be staged) and ACN_LDS_STACK=0|1 override. */
         size_t lds_max = 40960;
+        /* Round 4: nodes are staged only for scenes whose roots hold GENERIC nested compounds (hanging_lamps_in_row: compounds of
+         * CSG objects) -- the one traversal left that reads nodes per lane (compound_ray_hit_dev).  The lock-step machines read
+         * every node through scalar loads from global memory whatever is staged, and the leaves a root loop tests in line are
+         * better off with scalar loads too: a staged node comes back through ds_read into VGPRs (1080p wine_glass 51.8 -> 50.6 ms
+         * without staging, profiles/r04); the diamond's 40 KB of nodes had cost it the LDS stacks of its CSG machines. */
+        bool generic_compound = false;
+        for( int root : { scene->light_root, scene->matter_root } )
+        {
+            const acn_node& r = scene->nodes[ root ];
+            for( int32_t k = 0; k < r.child1; k++ )
+            {
+                const int32_t e = scene->elems[ r.child0 + k ];
+                if( scene->nodes[ e ].type == ACN_COMPOUND && !( nodes[ e ].flags & ACN_GFLAG_SIMPLE_COMPOUND ) ) generic_compound = true;
+            }
+        }
+        if( !generic_compound ) lds_max = 0;
         if( const char* e = getenv( "ACN_LDS_MAX" ) ) lds_max = ( size_t )atoll( e );
         size_t need = sizeof( GNode ) * ( size_t )scene->n_nodes;
         h->lds_bytes = need <= lds_max ? need : 0;
@@ -882,6 +909,10 @@ extern "C" void acn_scene_free( acn_scene_handle* h )
     for( auto& e : h->events ) { hipEventDestroy( e.a ); hipEventDestroy( e.b ); }
     if( h->ev0 ) hipEventDestroy( h->ev0 );
     if( h->ev1 ) hipEventDestroy( h->ev1 );
+    if( h->ev_fork ) hipEventDestroy( h->ev_fork );
+    if( h->ev_path ) hipEventDestroy( h->ev_path );
+    if( h->ev_join ) hipEventDestroy( h->ev_join );
+    if( h->side_stream ) hipStreamDestroy( h->side_stream );
     if( h->stream ) hipStreamDestroy( h->stream );
     delete h;
 }
@@ -1148,20 +1179,47 @@ static int render_chunk( acn_scene_handle* h, const double* d_pos_xy, size_t fir
             ACN_LAUNCH( h, 0, stream, acn_launch_walk( f, pass, pass + 1 == passes, qg, lds, stream, s, d_pos_xy, first_pixel, base,
                                                        level == 0 && pass == 0 ? cnt : 0u, order, h->d_accum, h->d_counters ) );
         }
-        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 0 ], cnt, 4u, h->shade_grid );
-        ACN_LAUNCH( h, 1, stream, acn_launch_shade64( f, qg, stream, s, h->d_accum, h->d_counters ) );
-        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 1 ], cnt, 16u, h->shade_grid );
-        ACN_LAUNCH( h, 1, stream, acn_launch_shade16( f, qg, stream, s, h->d_accum, h->d_counters ) );
-        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 2 ], cnt, 64u, h->shade_grid );
-        ACN_LAUNCH( h, 1, stream, acn_launch_shade4( f, qg, stream, s, h->d_accum, h->d_counters ) );
-        qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 3 ], cnt, 256u, h->shade_grid );
-        ACN_LAUNCH( h, 1, stream, acn_launch_shade1( f, qg, stream, s, h->d_accum, h->d_counters ) );
+        /* ACN_SHADE_FISSION=1 (off by default: measured slower, see Tunables).  The two sample loops of a shading point share
+         * nothing but the task record, so the level can fork: the direct-light loops and the shadow rays they defer on the side
+         * stream, the path loop and the path rays it defers on the main one.  The critical path of a level is then
+         * walk -> max( direct + hard_shadow, path + hard_path ) instead of their sum.  k_hard_shadow also takes the probes the path
+         * loop appends, so it waits for that launch (ev_path); the queues are the level's, so the next level waits for both.
+         * The last level of a frame casts no path rays (depth <= 10) and a frame without path samples has one level: no fork. */
+        const bool fork = h->tun.shade_fission && level + 1 < levels && h->side_stream != nullptr;
+        hipStream_t direct_stream = fork ? h->side_stream : stream;
+        if( fork )
+        {
+            HIP_TRY( hipEventRecord( h->ev_fork, stream ) );
+            HIP_TRY( hipStreamWaitEvent( h->side_stream, h->ev_fork, 0 ) );
+        }
+        for( int part = fork ? ACN_SHADE_DIRECT : ACN_SHADE_BOTH; part <= ( fork ? ACN_SHADE_PATH : ACN_SHADE_BOTH ); part++ )
+        {
+            hipStream_t part_stream = part == ACN_SHADE_DIRECT ? direct_stream : stream;
+            qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 0 ], cnt, 4u, h->shade_grid );
+            ACN_LAUNCH( h, 1, part_stream, acn_launch_shade64( f, qg, part_stream, s, h->d_accum, h->d_counters, part ) );
+            qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 1 ], cnt, 16u, h->shade_grid );
+            ACN_LAUNCH( h, 1, part_stream, acn_launch_shade16( f, qg, part_stream, s, h->d_accum, h->d_counters, part ) );
+            qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 2 ], cnt, 64u, h->shade_grid );
+            ACN_LAUNCH( h, 1, part_stream, acn_launch_shade4( f, qg, part_stream, s, h->d_accum, h->d_counters, part ) );
+            qg.shade_grid = learned_grid( h, h->seen_class[ level ][ 3 ], cnt, 256u, h->shade_grid );
+            ACN_LAUNCH( h, 1, part_stream, acn_launch_shade1( f, qg, part_stream, s, h->d_accum, h->d_counters, part ) );
+        }
+        if( fork )
+        {
+            HIP_TRY( hipEventRecord( h->ev_path, stream ) );
+            HIP_TRY( hipStreamWaitEvent( h->side_stream, h->ev_path, 0 ) );
+        }
         qg.grid = learned_grid( h, h->seen_hs[ level ], cnt, 256u, h->grid );
-        ACN_LAUNCH( h, 3, stream, acn_launch_hard_shadow( f, qg, lds, stream, s, h->d_accum, h->d_counters ) );
+        ACN_LAUNCH( h, 3, direct_stream, acn_launch_hard_shadow( f, qg, lds, direct_stream, s, h->d_accum, h->d_counters ) );
         if( level + 1 < levels )   /* the last level casts no path rays (depth <= 10) */
         {
             qg.grid = learned_grid( h, h->seen_hp[ level ], cnt, 256u, h->grid );
             ACN_LAUNCH( h, 3, stream, acn_launch_hard_path( f, qg, lds, stream, s, h->d_accum, h->d_counters ) );
+        }
+        if( fork )
+        {
+            HIP_TRY( hipEventRecord( h->ev_join, h->side_stream ) );
+            HIP_TRY( hipStreamWaitEvent( stream, h->ev_join, 0 ) );
         }
     }
     HIP_TRY( hipMemcpyAsync( h->h_counts, h->d_counts, sizeof( uint32_t ) * QC_N * levels, hipMemcpyDeviceToHost, stream ) );
@@ -1261,7 +1319,7 @@ static void set_rates( acn_scene_handle* h, uint32_t cnt, const uint32_t* fill, 
  * for itself and re-sized its queues in the middle of the frame.  A sample over the whole frame costs one short chain of
  * launches (a few ms; nothing next to a frame whose queues must be allocated anyway) and is trusted like a large chunk: the
  * queues are then sized ONCE, while the device is idle (launch_render; render_lanes for all lanes of a call). */
-static int learn_rates( acn_scene_handle* h, const double* d_pos_xy, size_t first, size_t n, hipStream_t stream )
+static int learn_rates( acn_scene_handle* h, const double* d_pos_xy, size_t first, size_t n, hipStream_t stream, size_t plan_positions, unsigned plan_grid )
 {
     if( rates_known( h ) || !h->tun.learn_sample || h->tun.chunk || h->tun.ws_uniform || n < 16384 ) return ACN_OK;
     int st = ensure_workspace( h, 4096 );   /* the starter set */
@@ -1300,7 +1358,37 @@ static int learn_rates( acn_scene_handle* h, const double* d_pos_xy, size_t firs
             fprintf( stderr, "[acn sample] %u positions (every %u-th) %s dead %.2f | per pos T %.1f C %.1f HS %.1f HP %.1f R %.1f\n", cnt, order.sample_stride, overflow ? "OVERFLOW" : "ok",
                      dead_share, fill[ 0 ] / ( double )cnt, fill[ 1 ] / ( double )cnt, fill[ 2 ] / ( double )cnt, fill[ 3 ] / ( double )cnt, fill[ 4 ] / ( double )cnt );
         if( overflow ) continue;
-        set_rates( h, cnt, fill, dead_share );
+        /* the records the sample left in each queue, exactly (marks minus dead slots; the fullest level counts, the queues are
+         * the levels' in turn), plus a quarter for what a sample of a few thousand positions does not see */
+        double live[ WQ_N ] = { 0, 0, 0, 0, 0 };
+        for( int level = 0; level < h->n_levels; level++ )
+        {
+            const uint32_t* c = h->h_counts + ( size_t )level * QC_N;
+            auto up = [ & ]( int q, double v ) { if( v > live[ q ] ) live[ q ] = v; };
+            up( WQ_TASKS, ( double )c[ QC_TASKS ] - ( double )c[ QS_DEAD_T ] );
+            up( WQ_CHILDREN, ( double )c[ QC_CHILDREN ] - ( double )c[ QS_DEAD_C ] );
+            up( WQ_HARD_SHADOW, ( double )c[ QS_HARD_SHADOW ] + ( double )c[ QS_PROBES ] );
+            up( WQ_HARD_PATH, ( double )c[ QC_HARD_PATH ] - ( double )c[ QS_DEAD_HP ] );
+            /* rays: no generation holds more than the largest mark, nor more than all the level's generations together */
+            double sum = 0, top = 0;
+            for( int g = 0; g <= ACN_MAX_WALK_PASSES; g++ ) { sum += c[ QC_GEN + g ]; if( c[ QC_GEN + g ] > top ) top = c[ QC_GEN + g ]; }
+            sum -= ( double )c[ QS_DEAD_R ];
+            up( WQ_RAYS, sum < top ? sum : top );
+        }
+        /* What a queue must hold is records PLUS the slots that die at the ends of the waves' reservations: up to 64 per wave,
+         * queue and launch that appends to it, whatever the chunk's size (a chunk of 230 000 positions of the wine glass marks 1.1 M
+         * task slots for 0.45 M tasks).  The planner's rates are marks per position, so the dead slots of a chunk of the size the
+         * call will run -- plan_positions, on persistent grids of plan_grid workgroups -- are spread over its positions:
+         * tasks, specular rays and probes are appended by k_shade_hits and ~4 walk passes, path-sample hits and the two deferred
+         * queues by the four k_shade launches (and k_hard_path). */
+        {
+            const double per_launch = 64.0 * 4.0 * ( double )plan_grid;
+            const double walkers = 5.0 * per_launch, shaders = 4.0 * per_launch;
+            const double dead[ WQ_N ] = { walkers, shaders + per_launch, walkers + shaders, shaders, walkers };
+            const double pp = ( double )( plan_positions < ACN_CHUNK_TARGET ? plan_positions : ACN_CHUNK_TARGET );
+            for( int q = 0; q < WQ_N; q++ ) h->rate[ q ] = f_max_host( 1.25 * live[ q ] / ( double )cnt + dead[ q ] / pp, 1e-3 );
+        }
+        if( h->tun.debug_chunks ) fprintf( stderr, "[acn sample] rates T %.1f C %.1f HS %.1f HP %.1f R %.1f\n", h->rate[ 0 ], h->rate[ 1 ], h->rate[ 2 ], h->rate[ 3 ], h->rate[ 4 ] );
         h->rate_cnt = 8192;   /* a sample of the whole frame: trusted like a chunk that size (launch_render re-sizes for the whole rest at once) */
         break;
     }
@@ -1326,7 +1414,7 @@ static int launch_render( acn_scene_handle* h, const double* d_pos_xy, size_t fi
     }
     else if( opts && opts->shard_mode > ACN_SHARD_SAMPLES ) return fail( ACN_ERR_ARG, "unknown shard_mode" );
     h->stage_timing = ( opts && ( opts->flags & ACN_OPT_STAGE_TIMING ) ) || h->tun.stage_timing;
-    int st = learn_rates( h, d_pos_xy, first, n, stream );
+    int st = learn_rates( h, d_pos_xy, first, n, stream, n, h->walk_grid > h->grid ? h->walk_grid : h->grid );
     if( st != ACN_OK ) return st;
     /* (shard fields again: the learning pass renders unsharded) */
     if( opts && opts->shard_mode == ACN_SHARD_SAMPLES && opts->shard_world > 1 ) { h->shard_rank = opts->shard_rank; h->shard_world = opts->shard_world; }
@@ -1528,8 +1616,12 @@ static int make_lane( acn_scene_handle* parent, int lanes, acn_scene_handle** ou
     l->walk_grid = parent->tun.walk_grid ? parent->tun.walk_grid : l->grid;
 #define HIP_TRY_L( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) { acn_scene_free( l ); return fail( ACN_ERR_DEVICE, hipGetErrorString( e_ ) ); } } while( 0 )
     HIP_TRY_L( hipStreamCreateWithFlags( &l->stream, hipStreamNonBlocking ) );
+    HIP_TRY_L( hipStreamCreateWithFlags( &l->side_stream, hipStreamNonBlocking ) );
     HIP_TRY_L( hipEventCreate( &l->ev0 ) );
     HIP_TRY_L( hipEventCreate( &l->ev1 ) );
+    HIP_TRY_L( hipEventCreateWithFlags( &l->ev_fork, hipEventDisableTiming ) );
+    HIP_TRY_L( hipEventCreateWithFlags( &l->ev_path, hipEventDisableTiming ) );
+    HIP_TRY_L( hipEventCreateWithFlags( &l->ev_join, hipEventDisableTiming ) );
     HIP_TRY_L( hipMalloc( &l->d_counters, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
     HIP_TRY_L( hipMemset( l->d_counters, 0, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
     HIP_TRY_L( hipMalloc( &l->d_counters_keep, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
@@ -1571,7 +1663,7 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
     if( !rates_known( h->lanes[ 0 ] ) )
     {
         h->budget_div = 1;
-        int st = learn_rates( h, d_pos_xy, first, n, stream );
+        int st = learn_rates( h, d_pos_xy, first, n, stream, n / ( size_t )lanes, h->lanes[ 0 ]->grid );
         if( st != ACN_OK ) return st;
         HIP_TRY( hipStreamSynchronize( stream ) );
         if( rates_known( h ) )
