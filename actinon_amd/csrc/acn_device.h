@@ -1346,14 +1346,15 @@ DEV double simple_compound_hit( const SC& sc, int cmp, V3 rp, V3 rd, V3* p_nor, 
     int i = sc.elems[ off ], end = i + sc.elems[ off + 1 ];
     double min_a = F3_INF;
     if( i >= end ) return min_a;
-    /* Every visit is a load the next one depends on (the entry decides where the walk goes), ~2 000 of them per path sample of
-     * many_spheres, each a round trip to L2.  A visit advances by ONE entry except where an enveloped compound is missed, so
-     * the entry behind the current one is requested before the current one is tested and is there when the walk gets to it:
-     * two loads in flight per lane instead of a chain of single ones.  (Same entries in the same order: same results.) */
+    /* Every visit is a load the next one depends on (the entry decides where the walk goes).  ACN_SC_PREFETCH requests the
+     * entry behind the current one before the current one is tested (a visit advances by ONE entry except where an enveloped
+     * compound is missed).  Measured and OFF: many_spheres p256, every 16th pixel of the 1080p frame, 1 577 ms without, 1 864 ms
+     * with (profiles/r04/ab_c3_prefetch.txt): half of the visits of a ray miss an enveloped compound and jump, so half of the
+     * prefetched 48 bytes are thrown away, and the walk is short of L2 bandwidth per lane, not of requests in flight. */
     SCEntry e = sc.sc_table[ i ];
     while( i < end )
     {
-#ifndef ACN_SC_NO_PREFETCH
+#ifdef ACN_SC_PREFETCH
         const SCEntry ahead = sc.sc_table[ i + 1 < end ? i + 1 : i ];
 #endif
         const bool miss = ( e.flags & ACN_NODE_HAS_ENVELOPE ) && !env_ray_hits_raw( ld3( e.env_pos ), e.env_radius, rp, rd, cnt );
@@ -1378,7 +1379,7 @@ DEV double simple_compound_hit( const SC& sc, int cmp, V3 rp, V3 rd, V3* p_nor, 
                 }
             }
         }
-#ifndef ACN_SC_NO_PREFETCH
+#ifdef ACN_SC_PREFETCH
         if( next == i + 1 ) e = ahead;
         else if( next < end ) e = sc.sc_table[ next ];
 #else

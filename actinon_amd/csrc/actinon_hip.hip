@@ -1383,10 +1383,14 @@ static int learn_rates( acn_scene_handle* h, const double* d_pos_xy, size_t firs
          * queues by the four k_shade launches (and k_hard_path). */
         {
             const double per_launch = 64.0 * 4.0 * ( double )plan_grid;
-            const double walkers = 5.0 * per_launch, shaders = 4.0 * per_launch;
-            const double dead[ WQ_N ] = { walkers, shaders + per_launch, walkers + shaders, shaders, walkers };
+            const double walkers = 3.0 * per_launch, shaders = 3.0 * per_launch;   /* (not every wave of every launch leaves a full reservation behind) */
+            const double dead[ WQ_N ] = { walkers, shaders, walkers + shaders, shaders, walkers };
             const double pp = ( double )( plan_positions < ACN_CHUNK_TARGET ? plan_positions : ACN_CHUNK_TARGET );
-            for( int q = 0; q < WQ_N; q++ ) h->rate[ q ] = f_max_host( 1.25 * live[ q ] / ( double )cnt + dead[ q ] / pp, 1e-3 );
+            /* a generation of specular rays is at most three children per shaded hit (path-sample hits of the level before, or the
+             * camera rays' shading points): the sample's ray marks are mostly dead slots */
+            const double ray_bound = 2.0 * live[ WQ_CHILDREN ] + live[ WQ_TASKS ];
+            if( live[ WQ_RAYS ] > ray_bound && ray_bound > 0 ) live[ WQ_RAYS ] = ray_bound;
+            for( int q = 0; q < WQ_N; q++ ) h->rate[ q ] = f_max_host( 1.2 * live[ q ] / ( double )cnt + dead[ q ] / pp, 1e-3 );
         }
         if( h->tun.debug_chunks ) fprintf( stderr, "[acn sample] rates T %.1f C %.1f HS %.1f HP %.1f R %.1f\n", h->rate[ 0 ], h->rate[ 1 ], h->rate[ 2 ], h->rate[ 3 ], h->rate[ 4 ] );
         h->rate_cnt = 8192;   /* a sample of the whole frame: trusted like a chunk that size (launch_render re-sizes for the whole rest at once) */
