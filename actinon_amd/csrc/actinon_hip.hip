@@ -82,7 +82,9 @@ struct Tunables
     unsigned walk_grid = 0;            /* ACN_WALK_GRID: workgroups of k_walk (256 VGPRs: two of its waves fill a SIMD's register file), 0 = as ACN_GRID */
     uint32_t stack_cap = 512;          /* ACN_STACK_CAP: private ray slots per k_walk wave */
     uint32_t fetch_walk = 64;          /* ACN_FETCH_WALK: fresh rays a k_walk wave reserves per cursor atomic */
-    uint32_t walk_passes = 12;         /* ACN_WALK_PASSES: launches of k_walk per path level (the last one finishes whatever is left) */
+    uint32_t walk_passes = 4;          /* ACN_WALK_PASSES: launches of k_walk per path level (the last one finishes whatever is left on the waves' private
+                                          stacks).  12 until round 4: with k_walk at 4 waves per SIMD the private tail is cheap and the launches are not --
+                                          1080p 52.0 -> 50.3 ms, the 1/8 share 13.7 -> 12.1, c2 28.2 -> 26.3, paraffin_lamp 367 -> 339 (profiles/r04/ab_walk_passes_*) */
     uint32_t private_limit = 32768;    /* ACN_PRIVATE_LIMIT: a generation of at most this many rays is finished on private stacks */
     bool     private_limit_set = false; /* ... given by the environment: then it holds for chunks of every size (render_chunk) */
     uint32_t class0_min = 0;           /* ACN_CLASS0_MIN: shading tasks with more samples than this take the 64-lane kernel, the others 16 / 4 / 1 lanes; 0: chosen per scene (acn_scene_upload) */
@@ -153,6 +155,7 @@ struct Workspace
     size_t      bytes = 0;          /* device memory of the queues and stacks */
     uint64_t    allocs = 0;         /* times this workspace was (re)allocated */
     bool        trimmed = false;    /* it was already re-allocated smaller once */
+    uint32_t    sized_calls = 0;    /* calls of ensure_workspace with learned rates (the trim window, see there) */
 };
 /* the queues of a pipeline run.  Each is sized from its OWN demand per sample position (learned, below): on the wine glass a
  * position leaves 15 deferred shadow rays but 2 shading points, and one common capacity -- the former layout -- made every
@@ -997,11 +1000,16 @@ static int ensure_workspace( acn_scene_handle* h, size_t n )
     for( int q = 0; q < WQ_N; q++ ) if( ( double )w.cap[ q ] < ( double )want[ q ] / 1.4 ) fits = false;
     /* ... and give back what the first, small chunks of a handle over-estimated (their dead slots do not scale): once, when
      * the rates come from a large chunk and the queues hold 40 % more than those ask for (slack included) */
-    if( fits && rates_known( h ) && !h->tun.ws_uniform && h->rate_cnt >= 32768 && !w.trimmed )
+    /* ... in a WINDOW: the first few sizing steps after the rates were learned (the second and third call of a handle).  Rates
+     * decay slowly towards what the chunks really leave, so without the window the condition could first become true ten frames
+     * later and put 100 ms of hipFree + hipMalloc into an arbitrary frame (round 4, session 10: the 1080p bench line read 68.6 ms
+     * instead of 51.8 because the trim fell into its ten timed steps) */
+    if( rates_known( h ) && h->rate_cnt >= 32768 ) w.sized_calls++;
+    if( fits && rates_known( h ) && !h->tun.ws_uniform && h->rate_cnt >= 32768 && !w.trimmed && w.sized_calls <= 3 )
     {
         size_t have = 0, need = 0;
         for( int q = 0; q < WQ_N; q++ ) { have += ( size_t )w.cap[ q ] * wq_bytes[ q ]; need += want[ q ] * wq_bytes[ q ]; }
-        if( ( double )have > 1.4 * ( double )need && have - need > ( ( size_t )1 << 30 ) ) { fits = false; trim = true; }
+        if( ( double )have > 1.25 * ( double )need && have - need > ( ( size_t )1 << 29 ) ) { fits = false; trim = true; }
     }
     if( fits ) return ACN_OK;
     const uint64_t allocs_before = w.allocs;
