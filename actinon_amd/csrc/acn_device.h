@@ -150,6 +150,7 @@ struct DevSceneT
     uint32_t prune_base; /* elems[ prune_base + node ]: offset of the node's prune program in elems[], or -1 */
     uint32_t class0_min; /* shading tasks with more samples than this run on 64 lanes (ACN_CLASS0_MIN, acn_pipeline.h: size_class) */
     const SCEntry* sc_table;   /* pre-order tables of the simple compounds */
+    CDblP env_tab;             /* per entry of elems[ 0 .. 2 n_elems ): envelope centre and radius of that element ( radius < 0: none ), see root_candidates */
     static constexpr bool prune = false;
 };
 /* the same scene for the "extras" kernel variants: interval-prune programs and in-line simple compounds.  Launched
@@ -164,7 +165,7 @@ __device__ __forceinline__ DevSceneT< NP2 > scene_rebind( const DevScene& sc, NP
     DevSceneT< NP2 > r;
     r.nodes = nodes; r.gnodes = sc.nodes; r.mats = sc.mats; r.elems = sc.elems; r.textures = sc.textures;
     r.light_root = sc.light_root; r.matter_root = sc.matter_root; r.n_nodes = sc.n_nodes; r.n_elems = sc.n_elems;
-    r.prm = sc.prm; r.camera_rotation = sc.camera_rotation; r.unit_f = sc.unit_f; r.flags = sc.flags; r.lds_stack = sc.lds_stack; r.prune_base = sc.prune_base; r.class0_min = sc.class0_min; r.sc_table = sc.sc_table;
+    r.prm = sc.prm; r.camera_rotation = sc.camera_rotation; r.unit_f = sc.unit_f; r.flags = sc.flags; r.lds_stack = sc.lds_stack; r.prune_base = sc.prune_base; r.class0_min = sc.class0_min; r.sc_table = sc.sc_table; r.env_tab = sc.env_tab;
     return r;
 }
 
@@ -1652,6 +1653,40 @@ DEVN double light_hit_call( SC sc, int e, V3 rp, V3 rd, CT* cnt )
     return element_hit< false >( sc, e, rp, rd, ( V3* )nullptr, &ho, -F3_INF, cnt );
 }
 
+/* Broad phase of a root loop (ACN_ROOT_CANDIDATES; built, measured, off).  A root compound of a lamp scene has 63 elements, and the loops below visit every one of them for
+ * every ray: element index -> node header -> envelope, three dependent scalar loads (~200 cycles each) before the envelope test
+ * that rejects the ray for nearly all of them (objects.c:264: a ray that misses an element's envelope gets f3_inf).  The
+ * envelopes of the slice elems[ first .. first + count ) lie side by side in env_tab (32 bytes per element, the same order), so
+ * this loop is independent loads the compiler overlaps, and its result -- bit i: the ray enters element i's envelope, or the
+ * element has none -- lets the loops skip an element NO lane of the wave needs without touching its node, and lets the other
+ * lanes sit an element out.  Results do not change: a skipped evaluation is one that returns f3_inf.  Elements from the 65th on
+ * are always candidates. */
+template< class SC, class CT >
+DEV uint64_t root_candidates( const SC& sc, int first, int count, V3 rp, V3 rd, CT* cnt )
+{
+    uint64_t m = 0;
+#ifndef ACN_ROOT_CANDIDATES   /* OFF: measured neutral on every workload (hanging_lamp 600x800 305 vs 308 ms, paraffin_lamp 335 - 346 both
+                                 ways, hanging_lamp 2160p every 256th pixel 4 639 vs 4 614 ms: profiles/r04/ab_root_candidates_s15.txt) -- the
+                                 root loop's chain of scalar loads is not what the lamp scenes wait for */
+    return ~0ull;
+#endif
+    const int n = count < 64 ? count : 64;
+    #pragma unroll 4
+    for( int i = 0; i < n; i++ )
+    {
+        const CDblP e = sc.env_tab + 4 * ( size_t )( first + i );
+        const double r = e[ 3 ];
+        bool cand = true;
+        if( r >= 0 )
+        {
+            cand = env_ray_hits_raw( mk( e[ 0 ], e[ 1 ], e[ 2 ] ), r, rp, rd, ACN_NO_CNT );
+            if( !cand ) { cnt->inc( CNT_OBJ_HIT ); cnt->cost( ACN_F_ENV_MISS ); }   /* what element_hit books for such a ray */
+        }
+        if( cand ) m |= 1ull << i;
+    }
+    return m;
+}
+
 /* compound_s_ray_hit on a root compound, any-hit form for occlusion tests: true iff some element hits at <= limit */
 template< class SC, class CT >
 DEV bool root_occluded( const SC& sc, int cmp, V3 rp, V3 rd, double limit, CT* cnt )
@@ -1659,14 +1694,22 @@ DEV bool root_occluded( const SC& sc, int cmp, V3 rp, V3 rd, double limit, CT* c
     auto o = &sc.nodes[ cmp ];
     if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) return false;
     int first = o->child0 + ( int )sc.n_elems, count = o->child1;   /* the cost-ordered copy: cheap elements first */
+    const uint64_t cand = root_candidates( sc, first, count, rp, rd, cnt );
+    bool occ = false;
     for( int i = 0; i < count; i++ )
     {
+        const bool mine = !occ && ( i >= 64 || ( ( cand >> i ) & 1ull ) );
+        if( __ballot( mine ) == 0ull ) continue;
         int element = __builtin_amdgcn_readfirstlane( sc.elems[ first + i ] );
-        int hit_obj;
-        double a = element_hit< false >( sc, element, rp, rd, nullptr, &hit_obj, limit, cnt );
-        if( a <= limit ) return true;
+        if( mine )
+        {
+            int hit_obj;
+            double a = element_hit< false >( sc, element, rp, rd, nullptr, &hit_obj, limit, cnt );
+            if( a <= limit ) occ = true;
+        }
+        if( __ballot( !occ ) == 0ull ) break;
     }
-    return false;
+    return occ;
 }
 
 struct Trans { V3 exit_nor; int exit_obj; int enter_obj; };
@@ -1680,12 +1723,16 @@ DEV double root_trans_hit( const SC& sc, int cmp, V3 rp, V3 rd, Trans* trans, CT
     if( node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) return F3_INF;
     double min_a = F3_INF;
     int first = o->child0, count = o->child1;
+    const uint64_t cand = root_candidates( sc, first, count, rp, rd, cnt );
     for( int i = 0; i < count; i++ )
     {
+        const bool mine = i >= 64 || ( ( cand >> i ) & 1ull );
+        if( __ballot( mine ) == 0ull ) continue;
         int element = __builtin_amdgcn_readfirstlane( sc.elems[ first + i ] );
         int hit_obj = -1;
         V3 nor = mk( 0, 0, 0 );
-        double a = element_hit< true >( sc, element, rp, rd, &nor, &hit_obj, -F3_INF, cnt );
+        double a = F3_INF;
+        if( mine ) a = element_hit< true >( sc, element, rp, rd, &nor, &hit_obj, -F3_INF, cnt );
         if( a < F3_INF )
         {
             cnt->cost( ACN_F_TRANS_RESOLVE );

@@ -76,7 +76,7 @@ struct Tunables
     size_t   workspace_mb = 0;         /* ACN_WORKSPACE_MB: upper bound of the queue workspace of one handle (all its lanes); 0: 64 GiB or a
                                           quarter of the device memory that is free at upload, whichever is less */
     size_t   chunk = 0;                /* ACN_CHUNK: sample positions per pipeline run, 0 = derived from the queue capacity */
-    int      lanes = 4;                /* ACN_LANES: concurrent pipeline runs of a large call */
+    int      lanes = 6;                /* ACN_LANES: concurrent pipeline runs of a large call (4 until round 4, each on grids twice the size: create_lane) */
     unsigned grid = 0;                 /* ACN_GRID: workgroups of the persistent kernels, 0 = 4 per compute unit */
     unsigned shade_grid = 0;           /* ACN_SHADE_GRID: workgroups of k_shade, 0 = 4 per compute unit */
     unsigned walk_grid = 0;            /* ACN_WALK_GRID: workgroups of k_walk (256 VGPRs: two of its waves fill a SIMD's register file), 0 = as ACN_GRID */
@@ -172,6 +172,7 @@ struct acn_scene_handle
     int32_t* d_elems = nullptr;
     acn_texture* d_textures = nullptr;
     SCEntry* d_sc_table = nullptr;
+    double* d_env_tab = nullptr;               /* envelopes of the compound slices, element by element (acn_device.h: root_candidates) */
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;         /* the direct-light half of a fissioned level and its deferred shadow rays (render_chunk) */
     hipEvent_t ev_fork = nullptr, ev_path = nullptr, ev_join = nullptr;
@@ -625,6 +626,17 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
             std::stable_sort( first, first + a.child1, [ & ]( int32_t x, int32_t y ) { return node_cost( x ) < node_cost( y ); } );
         }
     }
+    /* the envelope of every entry of elems[ 0 .. 2n ), in the same order: the broad phase of the root loops (root_candidates) */
+    std::vector< double > env_tab( 8 * ( size_t )scene->n_elems + 4, -1.0 );
+    for( size_t k = 0; k < 2 * ( size_t )scene->n_elems; k++ )
+    {
+        const acn_node& a = scene->nodes[ elems2[ k ] ];
+        if( a.flags & ACN_NODE_HAS_ENVELOPE )
+        {
+            for( int c = 0; c < 3; c++ ) env_tab[ 4 * k + c ] = a.env_pos[ c ];
+            env_tab[ 4 * k + 3 ] = a.env_radius;
+        }
+    }
     /* elems[ 2n .. 2n + n_nodes ): per node the offset of its interval-prune program (acn_device.h: prune_run) or -1,
      * followed by the programs.  Only root elements of compounds that are CSG composites with at least
      * ACN_PRUNE_MIN nodes get one (small trees are cheaper to walk than to pre-test). */
@@ -789,6 +801,9 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     HIP_TRY_H( hipMalloc( &h->d_sc_table, sizeof( SCEntry ) * ( sc_table.size() ? sc_table.size() : 1 ) ) );
     if( sc_table.size() ) HIP_TRY_H( hipMemcpy( h->d_sc_table, sc_table.data(), sizeof( SCEntry ) * sc_table.size(), hipMemcpyHostToDevice ) );
     h->dev.sc_table = h->d_sc_table;
+    HIP_TRY_H( hipMalloc( &h->d_env_tab, sizeof( double ) * env_tab.size() ) );
+    HIP_TRY_H( hipMemcpy( h->d_env_tab, env_tab.data(), sizeof( double ) * env_tab.size(), hipMemcpyHostToDevice ) );
+    h->dev.env_tab = ( CDblP )h->d_env_tab;
     /* Width of a shading task (size_class in acn_pipeline.h).  Narrow groups waste less of a sample loop's last round;
      * a whole wavefront per point keeps the rays of a round on one origin, which pays when a sample's traversal is long
      * and divergent (nested compounds, CSG objects with prune programs: the scenes of the "extras" kernel variants).
@@ -906,6 +921,7 @@ extern "C" void acn_scene_free( acn_scene_handle* h )
         if( h->d_elems ) hipFree( h->d_elems );
         if( h->d_textures ) hipFree( h->d_textures );
         if( h->d_sc_table ) hipFree( h->d_sc_table );
+        if( h->d_env_tab ) hipFree( h->d_env_tab );
     }
     if( h->d_counters ) hipFree( h->d_counters );
     if( h->d_counters_keep ) hipFree( h->d_counters_keep );
@@ -1623,8 +1639,12 @@ static int make_lane( acn_scene_handle* parent, int lanes, acn_scene_handle** ou
     l->prune = parent->prune; l->leaf_lights = parent->leaf_lights;
     l->tun = parent->tun; l->cus = parent->cus; l->n_levels = parent->n_levels;
     l->workspace_budget = parent->workspace_budget; l->n_lights = parent->n_lights;
-    l->grid = parent->tun.grid ? parent->tun.grid : parent->cus * 2u;
-    l->shade_grid = parent->tun.shade_grid ? parent->tun.shade_grid : parent->cus * 2u;
+    /* Round 4: six lanes on grids of ONE workgroup per CU (k_shade: one and a half) instead of four lanes on two.  With k_walk at
+     * four waves per SIMD a grid of 256 workgroups is resident at once, and six shorter chains fill each other's tails better than
+     * four: 1080p 50.2 -> 49.1 ms, c2 26.4 -> 25.0, and the share one of 8 GPUs gets 12.25 -> 11.4 ms (profiles/r04/ab_lanes6_*).
+     * A call that runs ALONE on the handle keeps four workgroups per CU (diamond on one lane: 2.3 s with them, 6.7 s with one). */
+    l->grid = parent->tun.grid ? parent->tun.grid : parent->cus * 1u;
+    l->shade_grid = parent->tun.shade_grid ? parent->tun.shade_grid : parent->cus * 3u / 2u;
     l->walk_grid = parent->tun.walk_grid ? parent->tun.walk_grid : l->grid;
 #define HIP_TRY_L( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) { acn_scene_free( l ); return fail( ACN_ERR_DEVICE, hipGetErrorString( e_ ) ); } } while( 0 )
     HIP_TRY_L( hipStreamCreateWithFlags( &l->stream, hipStreamNonBlocking ) );
