@@ -109,14 +109,30 @@ typedef double ACN_LDS* LdsF64P;
 typedef uint32_t ACN_LDS* LdsU32P;
 /* dynamic LDS of the machine kernels: [ staged node array (optional) ][ CSG stacks of the block's 256 lanes ] */
 extern __shared__ __attribute__( ( aligned( 16 ) ) ) double acn_lds_raw[];
+/* ACN_POOLED (acn_pipeline.h; built in round 4, measured slower, OFF): the machine kernels pool the rays of a workgroup's four
+ * waves per root element */
+#ifndef ACN_POOLED
+#define ACN_POOLED 0
+#endif
 #ifndef ACN_LDS_DEPTH
+#if ACN_POOLED
+#define ACN_LDS_DEPTH 2                 /* (the third level's 10 KB per workgroup go to the ray pool) */
+#else
 #define ACN_LDS_DEPTH 3                 /* stack levels kept in LDS; deeper nesting continues in scratch */
+#endif
 #endif
 #define ACN_LDS_LANES 256               /* block size of the kernels that provide the stack area */
 /* per level and lane: a 8 B, parked normal 24 B, w 4 B, side 4 B; doubles first (alignment):
  * [ a : D x 256 ][ nx, ny, nz : 3 x D x 256 ][ w : D x 256 ][ side : D x 256 ] */
 #define ACN_LDS_STACK_BYTES ( ACN_LDS_DEPTH * ACN_LDS_LANES * 40 )
 #define ACN_NO_LDS_STACK 0xFFFFFFFFu
+/* behind the stacks: the ray pool of the workgroup (pooled_machine_hit): six planes of 256 doubles (ray in / result out), one
+ * plane of 256 words (owners), two sets of the four waves' counts */
+#if ACN_POOLED
+#define ACN_LDS_POOL_BYTES ( 6 * ACN_LDS_LANES * 8 + ACN_LDS_LANES * 4 + 64 )
+#else
+#define ACN_LDS_POOL_BYTES 0
+#endif
 
 /* One entry of a simple compound's pre-order table (simple_compound_hit): everything a visit needs -- the element's
  * envelope, its type and the two links -- in ONE 48-byte record, i.e. one memory round trip per visited node instead
@@ -1954,6 +1970,187 @@ DEV double root_trans_hit_fast( const SC& sc, int cmp, V3 rp, V3 rd, Trans* tran
     }
     *hard = h;
     if( !h ) cnt->inc( CNT_TRANS_RAY );
+    return min_a;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* Pooled machines (ACN_POOLED=1; built, parity-green, measured SLOWER, off -- see the end of this comment).  A lock-step machine
+ * serves the lanes of ONE wave that meet the same root element, and the rays of a wave
+ * rarely agree on one: 18 of 64 lanes per entry on the wine glass, 4.4 on hanging_lamp (63 root elements), 7 in its k_hard_path
+ * (profiles/r04/phase_ticks_*.txt) -- the machine kernels of the lamp scenes ran at 7 - 10 % of their lanes.  The four waves of a
+ * workgroup now POOL the rays that need the same element: every lane with `need` writes its ray into the workgroup's pool in LDS
+ * (slots handed out by ballot + the waves' counts), the pooled rays are evaluated in batches of 64 by as few waves as it takes
+ * (in turn, so that the work spreads over the SIMDs), and every lane collects its result from its slot: one machine entry with
+ * up to 64 lanes instead of four with a quarter each.  A ray's own arithmetic is untouched -- which wave evaluates it is not
+ * part of any result.  ALL lanes of the workgroup must call (three barriers); the callers' loops are workgroup-uniform.
+ * Measured (profiles/r04/ab_pooled_s17.txt, same box, parity suite green with it): 1080p 49.9 -> 60.4 ms, hanging_lamp 600x800
+ * 307 -> 430, paraffin_lamp 340 -> 393, diamond every 16th pixel 2 245 -> 2 659.  Lanes per machine entry were the wrong target:
+ * the four waves ran their quarter-full machines SIDE BY SIDE on four SIMDs, and these kernels wait for latency, not for issue
+ * slots -- pooling puts the same evaluations one after another on one SIMD while three waves stand at a barrier. */
+struct RayPool
+{
+    LdsF64P v;          /* plane k of entry i: v[ k * 256 + i ]; in: origin 0 - 2, direction 3 - 5; out: a 0, normal 1 - 3 */
+    LdsU32P counts;     /* [ 2 ][ 4 ]: the waves' counts of the call at hand, double-buffered by the parity of `turn` */
+    uint32_t turn;      /* calls so far: parity of the counts, and the rotation of batches over the waves */
+};
+template< class SC > DEV RayPool ray_pool_of( const SC& sc )
+{
+    RayPool pl;
+    pl.v = ( LdsF64P )( ( char ACN_LDS* )acn_lds_raw + sc.lds_stack + ACN_LDS_STACK_BYTES );
+    pl.counts = ( LdsU32P )( pl.v + 6 * ACN_LDS_LANES ) + ACN_LDS_LANES;
+    pl.turn = 0;
+    return pl;
+}
+
+/* obj_ray_hit of root element e (a CSG / SDF object) for every lane of the WORKGROUP with `need`; f3_inf for the others */
+template< bool NOR, class SC, class CT >
+DEV double pooled_machine_hit( const SC& sc, RayPool& pl, int e, bool need, V3 rp, V3 rd, V3* nor, CT* cnt )
+{
+    const uint32_t wave = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )( threadIdx.x >> 6 ) );
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long m = __ballot( need );
+    const uint32_t par = ( pl.turn & 1u ) * 4u;
+    const uint32_t turn = pl.turn++;
+    if( lane == 0 ) pl.counts[ par + wave ] = ( uint32_t )__popcll( m );
+    __syncthreads();
+    uint32_t total = 0, off = 0;
+    for( uint32_t w = 0; w < 4u; w++ )
+    {
+        const uint32_t c = ( uint32_t )__builtin_amdgcn_readfirstlane( ( int )pl.counts[ par + w ] );
+        if( w < wave ) off += c;
+        total += c;
+    }
+    if( total == 0 ) return F3_INF;      /* the same in every wave of the workgroup */
+    const uint32_t slot = off + ( uint32_t )__builtin_amdgcn_mbcnt_hi( ( uint32_t )( m >> 32 ), __builtin_amdgcn_mbcnt_lo( ( uint32_t )m, 0u ) );
+    if( need )
+    {
+        pl.v[ slot ] = rp.x; pl.v[ ACN_LDS_LANES + slot ] = rp.y; pl.v[ 2 * ACN_LDS_LANES + slot ] = rp.z;
+        pl.v[ 3 * ACN_LDS_LANES + slot ] = rd.x; pl.v[ 4 * ACN_LDS_LANES + slot ] = rd.y; pl.v[ 5 * ACN_LDS_LANES + slot ] = rd.z;
+    }
+    __syncthreads();
+    for( uint32_t b = 0; b * 64u < total; b++ )
+    {
+        if( ( ( b + turn ) & 3u ) != wave ) continue;      /* batch b is this wave's turn */
+        const uint32_t idx = b * 64u + lane;
+        if( idx < total )
+        {
+            const V3 p = mk( pl.v[ idx ], pl.v[ ACN_LDS_LANES + idx ], pl.v[ 2 * ACN_LDS_LANES + idx ] );
+            const V3 d = mk( pl.v[ 3 * ACN_LDS_LANES + idx ], pl.v[ 4 * ACN_LDS_LANES + idx ], pl.v[ 5 * ACN_LDS_LANES + idx ] );
+            V3 n = mk( 0, 0, 0 );
+            const double a = obj_ray_hit_uni< NOR >( sref( sc ), e, p, d, &n, cnt );
+            pl.v[ idx ] = a;
+            if( NOR ) { pl.v[ ACN_LDS_LANES + idx ] = n.x; pl.v[ 2 * ACN_LDS_LANES + idx ] = n.y; pl.v[ 3 * ACN_LDS_LANES + idx ] = n.z; }
+        }
+    }
+    __syncthreads();
+    double a = F3_INF;
+    if( need )
+    {
+        a = pl.v[ slot ];
+        if( NOR && a < F3_INF ) *nor = mk( pl.v[ ACN_LDS_LANES + slot ], pl.v[ 2 * ACN_LDS_LANES + slot ], pl.v[ 3 * ACN_LDS_LANES + slot ] );
+    }
+    return a;
+}
+
+/* element_hit for the pooled root loops: `live` lanes want the element tested; machine elements go through the pool.  Every lane
+ * of the workgroup calls with the same e. */
+template< bool NOR, class SC, class CT >
+DEV double element_hit_pooled( const SC& sc, RayPool& pl, int e, bool live, V3 rp, V3 rd, V3* nor, int* hit_obj, double limit, CT* cnt )
+{
+    ACN_NODE_UNIFORM( n, &sc.nodes[ e ] )
+    const int type = n->type;
+    if( type == ACN_COMPOUND || type <= ACN_SQUAROID )
+    {
+        double a = F3_INF;
+        if( live ) a = element_hit< NOR >( sc, e, rp, rd, nor, hit_obj, limit, cnt );   /* no machine in these branches */
+        return a;
+    }
+    bool need = live;
+    if( need )
+    {
+        *hit_obj = e;
+        if( node_has_env( n ) && !env_ray_hits( n, rp, rd ) ) { cnt->inc( CNT_OBJ_HIT ); need = false; }
+        else if( type != ACN_DISTANCE && ( surely_outside< ACN_PRUNE_DEPTH >( sc, e, rp, rd ) || prune_run( sc, e, rp, rd, limit >= 0 ? limit : F3_INF ) ) ) { cnt->inc( CNT_OBJ_HIT ); need = false; }
+    }
+    return pooled_machine_hit< NOR >( sc, pl, e, need, rp, rd, nor, cnt );
+}
+
+/* root_occluded for the lanes with `want`, pooled */
+template< class SC, class CT >
+DEV bool root_occluded_pooled( const SC& sc, RayPool& pl, int cmp, bool want, V3 rp, V3 rd, double limit, CT* cnt )
+{
+    auto o = &sc.nodes[ cmp ];
+    if( want && node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) want = false;
+    int first = o->child0 + ( int )sc.n_elems, count = o->child1;   /* the cost-ordered copy: cheap elements first */
+    bool occ = false;
+    for( int i = 0; i < count; i++ )
+    {
+        int element = __builtin_amdgcn_readfirstlane( sc.elems[ first + i ] );
+        int hit_obj;
+        double a = element_hit_pooled< false >( sc, pl, element, want && !occ, rp, rd, ( V3* )nullptr, &hit_obj, limit, cnt );
+        if( a <= limit ) occ = true;
+    }
+    return occ;
+}
+
+/* root_trans_hit for the lanes with `live`, pooled */
+template< class SC, class CT >
+DEV double root_trans_hit_pooled( const SC& sc, RayPool& pl, int cmp, bool live, V3 rp, V3 rd, Trans* trans, CT* cnt )
+{
+    auto o = &sc.nodes[ cmp ];
+    if( live ) cnt->inc( CNT_TRANS_RAY );
+    if( live && node_has_env( o ) && !env_ray_hits( o, rp, rd ) ) live = false;
+    double min_a = F3_INF;
+    int first = o->child0, count = o->child1;
+    for( int i = 0; i < count; i++ )
+    {
+        int element = __builtin_amdgcn_readfirstlane( sc.elems[ first + i ] );
+        int hit_obj = -1;
+        V3 nor = mk( 0, 0, 0 );
+        double a = element_hit_pooled< true >( sc, pl, element, live, rp, rd, &nor, &hit_obj, -F3_INF, cnt );
+        if( a < F3_INF )
+        {
+            cnt->cost( ACN_F_TRANS_RESOLVE );
+            if( a < min_a - F3_EPS )
+            {
+                min_a = a;
+                if( v_mlv( nor, rd ) > 0 )
+                {
+                    trans->exit_nor = nor; trans->exit_obj = hit_obj; trans->enter_obj = -1;
+                }
+                else
+                {
+                    trans->exit_nor = v_neg( nor ); trans->exit_obj = -1; trans->enter_obj = hit_obj;
+                }
+            }
+            else if( f_abs( a - min_a ) < F3_EPS )
+            {
+                min_a = a < min_a ? a : min_a;
+                if( v_mlv( nor, rd ) > 0 ) trans->exit_obj = hit_obj;
+                else                       trans->enter_obj = hit_obj;
+            }
+        }
+    }
+    return min_a;
+}
+
+/* scene_s_trans_hit (scene.c:362-382) for the lanes with `live`, pooled: every lane of the workgroup calls */
+template< class SC, class CT >
+DEV double scene_trans_hit_pooled( const SC& sc, RayPool& pl, bool live, V3 rp, V3 rd, Trans* trans, CT* cnt )
+{
+    double min_a = F3_INF;
+    double a;
+    Trans trans_l;
+    trans_l.exit_nor = mk( 0, 0, 0 ); trans_l.exit_obj = -1; trans_l.enter_obj = -1;
+    #pragma unroll 1
+    for( int k = 0; k < 2; k++ )
+    {
+        if( ( a = root_trans_hit_pooled( sc, pl, k ? sc.matter_root : sc.light_root, live, rp, rd, &trans_l, cnt ) ) < min_a )
+        {
+            min_a = a;
+            *trans = trans_l;
+        }
+    }
     return min_a;
 }
 

@@ -690,6 +690,8 @@ DEV void wave_add_counters( unsigned long long*, const Cnt< false >& ) {}
 #ifndef ACN_TRACE_WAVES
 #define ACN_TRACE_WAVES ACN_WALK_WAVES
 #endif
+/* ACN_POOLED=1: the machine kernels pool the rays of a workgroup's four waves per root element (acn_device.h: pooled_machine_hit).
+ * Measured slower on every workload, off (defined in acn_device.h) */
 #ifndef ACN_HPATH_WAVES
 #define ACN_HPATH_WAVES ACN_WALK_WAVES
 #endif
@@ -767,13 +769,22 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
     range_init( fr, true );
     uint32_t traced = 0, steps = 0;
     bool finished = false;
+    RayPool pool = ray_pool_of( sc );
     for( uint32_t step = 0; step < ACN_WALK_MAX_STEPS; step++ )
     {
         /* the step's 64 rays: the top of the private stack, topped up with fresh input */
         uint32_t n_pop = sink.top < 64u ? sink.top : 64u;
         uint32_t n_fresh = 0, fb = 0;
         if( n_pop < 64u ) n_fresh = range_take( fr, cursor, fetch_batch, n_in, 64u - n_pop, &fb );
+#if ACN_POOLED
+        /* the waves of a workgroup step together (they pool their rays per root element): a wave that is out of work keeps
+         * stepping, with no rays, until all four are */
+        const bool have_rays = n_pop + n_fresh != 0;
+        if( !__syncthreads_or( have_rays ? 1 : 0 ) ) { finished = true; break; }
+#else
+        const bool have_rays = true;
         if( n_pop + n_fresh == 0 ) { finished = true; break; }
+#endif
         /* reservations this step may run dry: their atomics travel while the step's rays are traced (lane q: queue q of the
          * wave -- 0 tasks, 1 .. 4 the class lists, 5 the next generation's rays, 6 probes) */
         ChunkPrefetch pf;
@@ -812,17 +823,22 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
         }
         if( src && live ) { rp = src->p; rd = src->d; }
         if( live ) traced++;
-        steps++;
+        if( have_rays ) steps++;
 
         /* scene_s_trans_hit */
         Trans trans;
         trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
         double offs = F3_INF;
+#if ACN_POOLED
+        if constexpr( LDS ) offs = scene_trans_hit_pooled( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), pool, live, rp, rd, &trans, &cnt );
+        else                offs = scene_trans_hit_pooled( scene_view< PRUNE >( sc, sc.nodes ), pool, live, rp, rd, &trans, &cnt );
+#else
         if( live )
         {
             if constexpr( LDS ) offs = scene_trans_hit_dev( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), rp, rd, &trans, &cnt );
             else                offs = scene_trans_hit_dev( scene_view< PRUNE >( sc, sc.nodes ), rp, rd, &trans, &cnt );
         }
+#endif
         chunk_prefetch_park( cs + ( lane < 7 ? lane : 0 ), pf );
         /* what the ray carries is read only now, so that it does not occupy registers across the traversal */
         asm volatile( "" ::: "memory" );
@@ -1327,6 +1343,37 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
     fetch_batch = balanced_batch( n, fetch_batch, 64u );
     FetchRange fr;
     range_init( fr, n > 0 );
+#if ACN_POOLED
+    RayPool pool = ray_pool_of( sc );
+    for( ;; )
+    {
+        uint32_t first = 0;
+        uint32_t got = range_take( fr, p_counts + QC_CUR_HS, fetch_batch, n, 64u, &first );
+        if( !__syncthreads_or( got != 0 ? 1 : 0 ) ) break;   /* the four waves of the workgroup pool their rays: they leave together */
+        HardShadow r;
+        r.pos = mk( 0, 0, 0 ); r.d = mk( 0, 0, 1 ); r.limit = 0; r.contrib = mk( 0, 0, 0 ); r.pixel = ACN_INVALID; r.pad = 0;
+        if( ( threadIdx.x & 63 ) < got ) r = recs[ first + ( threadIdx.x & 63 ) ];
+        const bool live = r.pixel != ACN_INVALID;
+        bool occ = false;
+        ACN_LAP( PH_FETCH );
+        /* a probe of a specular ray (probe_push) asks scene_s_trans_hit's question: the lights count as well.
+         * One call site for both roots (the traversal with the CSG machine is in-line code). */
+        #pragma unroll 1
+        for( int k = 0; k < 2; k++ )
+        {
+            const int root = k ? sc.matter_root : sc.light_root;
+            const bool want = live && !occ && ( k == 1 || ( r.pad & 1u ) );
+            if( !__syncthreads_or( want ? 1 : 0 ) ) continue;
+            bool o2;
+            if constexpr( LDS ) o2 = root_occluded_pooled( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), pool, root, want, r.pos, r.d, r.limit, &cnt );
+            else                o2 = root_occluded_pooled( scene_view< PRUNE >( sc, sc.nodes ), pool, root, want, r.pos, r.d, r.limit, &cnt );
+            if( want && o2 ) occ = true;
+        }
+        ACN_LAP( PH_ROOT_LEAF );
+        if( live && !occ ) { cnt.cost( ACN_F_DIRECT_TAIL ); pixel_add( accum, sc.flags, r.pixel, r.contrib ); }
+        ACN_LAP( PH_SHADE );
+    }
+#else
     for( ;; )
     {
         uint32_t first = 0;
@@ -1339,8 +1386,6 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
             {
                 bool occ = false;
                 ACN_LAP( PH_FETCH );
-                /* a probe of a specular ray (probe_push) asks scene_s_trans_hit's question: the lights count as well.
-                 * One call site for both roots (the traversal with the CSG machine is in-line code). */
                 #pragma unroll 1
                 for( int k = 0; k < 2; k++ )
                 {
@@ -1359,6 +1404,7 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
             }
         }
     }
+#endif
     ACN_LAP( PH_TAIL );
     ACN_PHASE_FLUSH( counters, 1 )
     wave_add_counters( counters, cnt );
@@ -1390,11 +1436,16 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
     auto kill_ch = [ p_children ]( uint32_t k ) { p_children[ k ].pixel = ACN_INVALID; };
     FetchRange fr;
     range_init( fr, n > 0 );
+    RayPool pool = ray_pool_of( sc );
     for( ;; )
     {
         uint32_t first = 0;
         uint32_t got = range_take( fr, p_counts + QC_CUR_HP, fetch_batch, n, 64u, &first );
+#if ACN_POOLED
+        if( !__syncthreads_or( got != 0 ? 1 : 0 ) ) break;   /* the four waves of the workgroup pool their rays: they leave together */
+#else
         if( got == 0 ) break;
+#endif
         bool hit = false;
         HardPath r;
         r.pos = mk( 0, 0, 0 ); r.d = mk( 0, 0, 1 ); r.T = mk( 0, 0, 0 ); r.intensity = 0; r.depth = 0; r.pixel = ACN_INVALID;
@@ -1402,11 +1453,17 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
         trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
         double a = F3_INF;
         if( ( threadIdx.x & 63 ) < got ) r = recs[ first + ( threadIdx.x & 63 ) ];
+#if ACN_POOLED
+        if constexpr( LDS ) a = root_trans_hit_pooled( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), pool, sc.matter_root, r.pixel != ACN_INVALID, r.pos, r.d, &trans, &cnt );
+        else                a = root_trans_hit_pooled( scene_view< PRUNE >( sc, sc.nodes ), pool, sc.matter_root, r.pixel != ACN_INVALID, r.pos, r.d, &trans, &cnt );
+#endif
         if( r.pixel != ACN_INVALID )
         {
             ACN_LAP( PH_FETCH );
+#if !ACN_POOLED
             if constexpr( LDS ) a = root_trans_hit( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, &trans, &cnt );
             else                a = root_trans_hit( scene_view< PRUNE >( sc, sc.nodes ), sc.matter_root, r.pos, r.d, &trans, &cnt );
+#endif
             ACN_LAP( PH_ROOT_LEAF );
             hit = a < sc.prm.max_path_length;
             if( !hit )

@@ -863,10 +863,10 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
         if( !generic_compound ) lds_max = 0;
         if( const char* e = getenv( "ACN_LDS_MAX" ) ) lds_max = ( size_t )atoll( e );
         size_t need = sizeof( GNode ) * ( size_t )scene->n_nodes;
-        h->lds_bytes = need <= lds_max ? need : 0;
-        bool stack = h->lds_bytes == 0 || h->lds_bytes + ACN_LDS_STACK_BYTES <= 40960;
-        if( const char* e = getenv( "ACN_LDS_STACK" ) ) stack = atoi( e ) != 0;
-        h->lds_stack_bytes = stack ? ACN_LDS_STACK_BYTES : 0;
+        /* every machine kernel owns the stacks AND the ray pool of its workgroup (pooled_machine_hit); nodes are staged in front
+         * of them only if the three fit 40 KB (four workgroups per CU) */
+        h->lds_bytes = need <= lds_max && need + ACN_LDS_STACK_BYTES + ACN_LDS_POOL_BYTES <= 40960 ? need : 0;
+        h->lds_stack_bytes = ACN_LDS_STACK_BYTES + ACN_LDS_POOL_BYTES;
     }
     h->dev.flags = h->d_counts + QC_FLAGS;
     h->dev.lds_stack = h->lds_stack_bytes ? 0u : ACN_NO_LDS_STACK;   /* the kernels that own a stack area set the offset */
