@@ -443,7 +443,10 @@ def main():
                        "pixels": n_pix, "path_samples": S,
                        "pixel_subset": (f"every {args.pixel_stride}th pixel of the {W}x{H} raster" if args.pixel_stride > 1 else
                                         f"rows {args.rows} of the {W}x{H} raster" if args.rows else "all"),
-                       "split": args.split if world > 1 else "none", "partition": partition, "exchange": exchange},
+                       "split": args.split if world > 1 else "none", "partition": partition, "exchange": exchange,
+                       # what torch.distributed actually ran on (N > 1): "nccl" is RCCL on ROCm; world size as the process group saw it
+                       "backend": (dist.get_backend() if world > 1 else None), "world_size": (dist.get_world_size() if world > 1 else 1),
+                       "parallelism": (f"{args.split}{world}" if world > 1 else "none")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, world),
                          "kernel": "one main pass = the launch chain k_walk passes / k_shade x 4 size classes / k_hard_shadow / k_hard_path / "
@@ -455,7 +458,7 @@ def main():
                                                          "k_hard_*": stages["hard_ms"], "k_finalize": stages["finalize_ms"]},
                          "workspace_bytes": stages.get("workspace_bytes"),
                          "traffic_profile": "profiles/traffic.json (stamped with the kernel source hash; null when stale)",
-                         "note": "the path is fp64-VALU-issue bound with divergent CSG traversal; the HBM roofline is "
+                         "note": "the path is fp64 arithmetic with divergent CSG traversal, bound by latency (DESIGN.md 4d); the HBM roofline is "
                                  "reported because BASELINE.json asks for it (DESIGN.md 7)"},
             "roofline_fp64": None if counters is None else {
                 "bound": "fp64 vector ALU (no MFMA: the path has no dense contraction)",

@@ -19,7 +19,7 @@ json.dump({"wine_glass_1080p": t, "_note": old.get("_note", "")}, open(os.path.j
 for f in glob.glob(os.path.join(D, "bench_*.json")) + glob.glob(os.path.join(D, "checksum_*.json")) + [os.path.join(D, x) for x in ("traffic_by_kernel.txt", "tests_gpu.log", "smoke.log", "frames.txt")]:
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, os.path.basename(f)))
-for src, dst in (("stats4", "wine_glass_1080p_4lanes_kernel_stats.csv"), ("stats1", "wine_glass_1080p_1lane_kernel_stats.csv")):
+for src, dst in (("stats4", "wine_glass_1080p_6lanes_kernel_stats.csv"), ("stats1", "wine_glass_1080p_1lane_kernel_stats.csv")):
     f = glob.glob(os.path.join(D, src, "**", "*kernel_stats.csv"), recursive=True)
     if f:
         shutil.copy(f[0], os.path.join(P, dst))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The round's closing measurements on one MI355X box (run through gpurun): GPU tests, smoke, the headline bench line with CPU
-# baseline and frame digest, kernel-trace summaries with 4 lanes and with one, HBM traffic (two PMC passes), 2-rank rehearsals of
+# baseline and frame digest, kernel-trace summaries with the default lanes and with one, HBM traffic (two PMC passes), 2-rank rehearsals of
 # both splits, the small configs.   usage: scripts/final_measure_r04.sh <outdir under gpurun_out/>
 out=gpurun_out/$1; mkdir -p $out
 export TMPDIR=/tmp
