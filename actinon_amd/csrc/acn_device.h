@@ -133,6 +133,15 @@ extern __shared__ __attribute__( ( aligned( 16 ) ) ) double acn_lds_raw[];
 #else
 #define ACN_LDS_POOL_BYTES 0
 #endif
+/* behind those: the ray origin of the lock-step machine at hand, one per lane (OrgLds): three planes of 256 doubles */
+#ifndef ACN_PARK_ORIGIN
+#define ACN_PARK_ORIGIN 1
+#endif
+#if ACN_PARK_ORIGIN
+#define ACN_LDS_ORG_BYTES ( 3 * ACN_LDS_LANES * 8 )
+#else
+#define ACN_LDS_ORG_BYTES 0
+#endif
 
 /* One entry of a simple compound's pre-order table (simple_compound_hit): everything a visit needs -- the element's
  * envelope, its type and the two links -- in ONE 48-byte record, i.e. one memory round trip per visited node instead
@@ -168,10 +177,12 @@ struct DevSceneT
     const SCEntry* sc_table;   /* pre-order tables of the simple compounds */
     CDblP env_tab;             /* per entry of elems[ 0 .. 2 n_elems ): envelope centre and radius of that element ( radius < 0: none ), see root_candidates */
     static constexpr bool prune = false;
+    static constexpr bool park = false;   /* the lock-step machines keep the ray origin in LDS (OrgLds): only where the kernel owns the slot */
 };
 /* the same scene for the "extras" kernel variants: interval-prune programs and in-line simple compounds.  Launched
  * only when the upload step produced either, so that the kernels of plain scenes (wine_glass) do not carry their code */
 template< class NP > struct DevScenePT : DevSceneT< NP > { static constexpr bool prune = true; };
+template< class BASE > struct ParkedScene : BASE { static constexpr bool park = true; };
 typedef DevSceneT< NodeP > DevScene;
 
 /* the same scene with its node array read from another address space */
@@ -185,11 +196,19 @@ __device__ __forceinline__ DevSceneT< NP2 > scene_rebind( const DevScene& sc, NP
     return r;
 }
 
-template< bool PR, class NP2 >
+template< bool PR, bool PK = false, class NP2 >
 __device__ __forceinline__ auto scene_view( const DevScene& sc, NP2 nodes )
 {
-    if constexpr( PR ) { DevScenePT< NP2 > r; static_cast< DevSceneT< NP2 >& >( r ) = scene_rebind( sc, nodes ); return r; }
-    else return scene_rebind( sc, nodes );
+    if constexpr( PR )
+    {
+        if constexpr( PK ) { ParkedScene< DevScenePT< NP2 > > r; static_cast< DevSceneT< NP2 >& >( r ) = scene_rebind( sc, nodes ); return r; }
+        else               { DevScenePT< NP2 > r; static_cast< DevSceneT< NP2 >& >( r ) = scene_rebind( sc, nodes ); return r; }
+    }
+    else
+    {
+        if constexpr( PK ) { ParkedScene< DevSceneT< NP2 > > r; static_cast< DevSceneT< NP2 >& >( r ) = scene_rebind( sc, nodes ); return r; }
+        else return scene_rebind( sc, nodes );
+    }
 }
 
 enum
@@ -771,11 +790,27 @@ template< class NP, class CT > DEV int simple_leaf_side_( NP g, V3 pos, CT* cnt 
 }
 #define simple_leaf_side( ... ) simple_leaf_side_( __VA_ARGS__, cnt )
 
+/* Where a ray's ORIGIN lives while a CSG object is evaluated.  The machines of k_walk run at 128 VGPRs, and the value the
+ * allocator gives up first is the origin of the step's ray: stored to scratch once and re-loaded at 97 places -- every leaf and
+ * envelope test at a frame the ray enters unchanged (ISA of round 4, scripts/isa_scratch.py) -- ~60 % of the kernel's scratch loads
+ * and most of its 22 GB per frame.  It is one value per lane for the whole evaluation of a frame, so the lock-step machine parks
+ * it in LDS (three planes of 256 doubles behind the stacks and the pool) and the operand code reads it where it uses it: a
+ * ds_read, ~64 cycles, no VMEM slot.  A pair's alternating walk continues from a DERIVED origin that lives for one operand
+ * evaluation: a plain V3.  The operand / pair code takes either through org_get(). */
+struct OrgLds
+{
+    volatile double ACN_LDS* p;
+    DEV V3 get() const { return mk( p[ 0 ], p[ ACN_LDS_LANES ], p[ 2 * ACN_LDS_LANES ] ); }
+    DEV void set( V3 v ) const { p[ 0 ] = v.x; p[ ACN_LDS_LANES ] = v.y; p[ 2 * ACN_LDS_LANES ] = v.z; }
+};
+DEV V3 org_get( const V3& v ) { return v; }
+DEV V3 org_get( const OrgLds& o ) { return o.get(); }
+
 /* Pairs of level L: both operands are a simple leaf, NEG( simple leaf ) or -- for L = 2 -- a level-1 pair.  The
  * functions below are the reference's obj_side / obj_ray_hit for such operands and pairs, recursion unrolled by L.
  * (Level-1 operands as real function calls instead of in-line expansion: 69.4 vs 57.4 ms on c2 -- calls spill.) */
 template< int L, class SR, class NP, class CT > DEV int pair_side( SR sc, NP n, V3 pos, CT* cnt );
-template< int L, bool SPLIT = false, class SR, class NP, class CT > DEV double pair_hit( SR sc, NP n, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt );
+template< int L, bool SPLIT = false, class SR, class NP, class O, class CT > DEV double pair_hit( SR sc, NP n, O rp, V3 rd, bool want_nor, V3* nor, CT* cnt );
 
 /* An operand that is NEG( simple leaf ) goes through the SAME copy of the leaf code as a plain one (the leaf's node is selected,
  * the sign applied afterwards): every in-line copy of an operand is one plane / sphere / squaroid routine, not two. */
@@ -808,17 +843,17 @@ template< class NP, class CT > DEV double simple_leaf_hit_( NP g, V3 rp, V3 rd, 
 }
 #define simple_leaf_hit( ... ) simple_leaf_hit_( __VA_ARGS__, cnt )
 
-template< int L, bool SPLIT = false, class SR, class CT > DEV double operand_hit( SR sc, int c, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
+template< int L, bool SPLIT = false, class SR, class O, class CT > DEV double operand_hit( SR sc, int c, O rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
 {
     const auto cn = &sc.nodes[ c ];
     cnt->inc( CNT_OBJ_HIT );
-    if( node_has_env( cn ) && !env_ray_hits( cn, rp, rd ) ) return F3_INF;
+    if( node_has_env( cn ) && !env_ray_hits( cn, org_get( rp ), rd ) ) return F3_INF;
     if constexpr( L > 1 )
     {
         if( cn->flags & ACN_GFLAG_LEAF_PAIR )
         {
             double a = pair_hit< L - 1, SPLIT >( sc, cn, rp, rd, want_nor, nor, cnt );
-            if( want_nor && a < F3_INF && cn->surface_roughness > 0 ) *nor = roughness_normal( cn, *nor, ray_pos( rp, rd, a ) );
+            if( want_nor && a < F3_INF && cn->surface_roughness > 0 ) *nor = roughness_normal( cn, *nor, ray_pos( org_get( rp ), rd, a ) );
             return a;
         }
     }
@@ -827,13 +862,13 @@ template< int L, bool SPLIT = false, class SR, class CT > DEV double operand_hit
     if( neg )
     {
         cnt->inc( CNT_OBJ_HIT );
-        if( node_has_env( g ) && !env_ray_hits( g, rp, rd ) ) return F3_INF;
+        if( node_has_env( g ) && !env_ray_hits( g, org_get( rp ), rd ) ) return F3_INF;
     }
-    const double a = simple_leaf_hit( g, rp, rd, want_nor, nor );
+    const double a = simple_leaf_hit( g, org_get( rp ), rd, want_nor, nor );
     if( neg && a < F3_INF && want_nor )
     {
         *nor = v_neg( *nor );                                                                  /* objects.c:1329-1339 */
-        if( cn->surface_roughness > 0 ) *nor = roughness_normal( cn, *nor, ray_pos( rp, rd, a ) );
+        if( cn->surface_roughness > 0 ) *nor = roughness_normal( cn, *nor, ray_pos( org_get( rp ), rd, a ) );
     }
     return a;
 }
@@ -855,7 +890,7 @@ template< int L, class SR, class NP, class CT > DEV int pair_side( SR sc, NP n, 
  * operand code, entered by the lanes whose turn it is: two copies of operand_hit and two of operand_side per pair where
  * round 3 had four of each, a quarter of the code two levels deep.  A lane's own sequence of evaluations, and with it every
  * bit of its result, is the reference's. */
-template< int L, bool SPLIT, class SR, class NP, class CT > DEV double pair_hit( SR sc, NP n, V3 rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
+template< int L, bool SPLIT, class SR, class NP, class O, class CT > DEV double pair_hit( SR sc, NP n, O rp, V3 rd, bool want_nor, V3* nor, CT* cnt )
 {
     const int want = ( n->type == ACN_PAIR_INSIDE ) ? -1 : 1;
     const int c0 = n->child0, c1 = n->child1;
@@ -882,7 +917,7 @@ template< int L, bool SPLIT, class SR, class NP, class CT > DEV double pair_hit(
             {
                 cnt->cost( ACN_F_PAIR_STEP );
                 const double ac = k ? a2 : a1;
-                if( operand_side< L >( sc, k ? c0 : c1, ray_pos( rp, rd, ac ), cnt ) == want ) { open = false; res = ac; if( want_nor ) *nor = k ? n2 : n1; }
+                if( operand_side< L >( sc, k ? c0 : c1, ray_pos( org_get( rp ), rd, ac ), cnt ) == want ) { open = false; res = ac; if( want_nor ) *nor = k ? n2 : n1; }
             }
             else if( !k ) cnt->cost( ACN_F_PAIR_STEP );
         }
@@ -893,7 +928,7 @@ template< int L, bool SPLIT, class SR, class NP, class CT > DEV double pair_hit(
         bool swapped = false;
         for( ;; )
         {
-            const V3 walk_p = ray_pos( rp, rd, offs );
+            const V3 walk_p = ray_pos( org_get( rp ), rd, offs );
             double a = F3_INF;
             int sd = 0;
             #pragma unroll 1
@@ -919,15 +954,15 @@ template< int L, bool SPLIT, class SR, class NP, class CT > DEV double pair_hit(
         double a1 = operand_hit< L, SPLIT >( sc, c0, rp, rd, want_nor, &n1, cnt );
         double a2 = operand_hit< L, SPLIT >( sc, c1, rp, rd, want_nor, &n2, cnt );
         cnt->cost( ACN_F_PAIR_STEP );
-        if( a1 < a2 && operand_side< L >( sc, c1, ray_pos( rp, rd, a1 ), cnt ) == want ) { *nor = n1; return a1; }
+        if( a1 < a2 && operand_side< L >( sc, c1, ray_pos( org_get( rp ), rd, a1 ), cnt ) == want ) { *nor = n1; return a1; }
         if( a2 >= F3_INF ) return F3_INF;
         cnt->cost( ACN_F_PAIR_STEP );
-        if( operand_side< L >( sc, c0, ray_pos( rp, rd, a2 ), cnt ) == want ) { *nor = n2; return a2; }
+        if( operand_side< L >( sc, c0, ray_pos( org_get( rp ), rd, a2 ), cnt ) == want ) { *nor = n2; return a2; }
         double offs = a2;
         bool swapped = false;
         for( ;; )
         {
-            V3 walk_p = ray_pos( rp, rd, offs );
+            V3 walk_p = ray_pos( org_get( rp ), rd, offs );
             double a = operand_hit< L, SPLIT >( sc, swapped ? c1 : c0, walk_p, rd, want_nor, &n1, cnt );
             cnt->cost( ACN_F_PAIR_STEP );
             if( a >= F3_INF ) return F3_INF;
@@ -1646,7 +1681,7 @@ DEV double element_hit( const SC& sc, int e, V3 rp, V3 rd, V3* nor, int* hit_obj
         if( type != ACN_DISTANCE && ( surely_outside< ACN_PRUNE_DEPTH >( sc, e, rp, rd ) || prune_run( sc, e, rp, rd, F3_INF ) ) ) { cnt->inc( CNT_OBJ_HIT ); ACN_LAP( PH_PRUNE ); return F3_INF; }
         ACN_LAP( PH_PRUNE );
 #if ACN_UNI_MACHINE
-        return obj_ray_hit_uni< NOR >( sref( sc ), e, rp, rd, nor, cnt );   /* the machine redoes the envelope test */
+        return obj_ray_hit_uni< NOR, SC::park >( sref( sc ), e, rp, rd, nor, cnt );   /* the machine redoes the envelope test */
 #else
         return obj_ray_hit_dev( sref( sc ), e, rp, rd, NOR, nor, cnt );
 #endif

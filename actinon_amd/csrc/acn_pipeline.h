@@ -830,13 +830,13 @@ void k_walk( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const RayTask* __restrict__ ray
         trans.exit_nor = mk( 0, 0, 0 ); trans.exit_obj = -1; trans.enter_obj = -1;
         double offs = F3_INF;
 #if ACN_POOLED
-        if constexpr( LDS ) offs = scene_trans_hit_pooled( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), pool, live, rp, rd, &trans, &cnt );
-        else                offs = scene_trans_hit_pooled( scene_view< PRUNE >( sc, sc.nodes ), pool, live, rp, rd, &trans, &cnt );
+        if constexpr( LDS ) offs = scene_trans_hit_pooled( scene_view< PRUNE, ACN_PARK_ORIGIN != 0 >( sc, ( LdsNodeP )acn_lds_raw ), pool, live, rp, rd, &trans, &cnt );
+        else                offs = scene_trans_hit_pooled( scene_view< PRUNE, ACN_PARK_ORIGIN != 0 >( sc, sc.nodes ), pool, live, rp, rd, &trans, &cnt );
 #else
         if( live )
         {
-            if constexpr( LDS ) offs = scene_trans_hit_dev( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), rp, rd, &trans, &cnt );
-            else                offs = scene_trans_hit_dev( scene_view< PRUNE >( sc, sc.nodes ), rp, rd, &trans, &cnt );
+            if constexpr( LDS ) offs = scene_trans_hit_dev( scene_view< PRUNE, ACN_PARK_ORIGIN != 0 >( sc, ( LdsNodeP )acn_lds_raw ), rp, rd, &trans, &cnt );
+            else                offs = scene_trans_hit_dev( scene_view< PRUNE, ACN_PARK_ORIGIN != 0 >( sc, sc.nodes ), rp, rd, &trans, &cnt );
         }
 #endif
         chunk_prefetch_park( cs + ( lane < 7 ? lane : 0 ), pf );
@@ -1365,8 +1365,8 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
             const bool want = live && !occ && ( k == 1 || ( r.pad & 1u ) );
             if( !__syncthreads_or( want ? 1 : 0 ) ) continue;
             bool o2;
-            if constexpr( LDS ) o2 = root_occluded_pooled( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), pool, root, want, r.pos, r.d, r.limit, &cnt );
-            else                o2 = root_occluded_pooled( scene_view< PRUNE >( sc, sc.nodes ), pool, root, want, r.pos, r.d, r.limit, &cnt );
+            if constexpr( LDS ) o2 = root_occluded_pooled( scene_view< PRUNE, ACN_PARK_ORIGIN != 0 >( sc, ( LdsNodeP )acn_lds_raw ), pool, root, want, r.pos, r.d, r.limit, &cnt );
+            else                o2 = root_occluded_pooled( scene_view< PRUNE, ACN_PARK_ORIGIN != 0 >( sc, sc.nodes ), pool, root, want, r.pos, r.d, r.limit, &cnt );
             if( want && o2 ) occ = true;
         }
         ACN_LAP( PH_ROOT_LEAF );
@@ -1394,8 +1394,8 @@ void k_hard_shadow( ACN_SCENE_PARAMS, const HardShadow* __restrict__ recs, uint3
                     if( __ballot( want ) == 0ull ) continue;
                     if( want )
                     {
-                        if constexpr( LDS ) occ = root_occluded( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), root, r.pos, r.d, r.limit, &cnt );
-                        else                occ = root_occluded( scene_view< PRUNE >( sc, sc.nodes ), root, r.pos, r.d, r.limit, &cnt );
+                        if constexpr( LDS ) occ = root_occluded( scene_view< PRUNE, ACN_PARK_ORIGIN != 0 >( sc, ( LdsNodeP )acn_lds_raw ), root, r.pos, r.d, r.limit, &cnt );
+                        else                occ = root_occluded( scene_view< PRUNE, ACN_PARK_ORIGIN != 0 >( sc, sc.nodes ), root, r.pos, r.d, r.limit, &cnt );
                     }
                 }
                 ACN_LAP( PH_ROOT_LEAF );
@@ -1454,15 +1454,15 @@ void k_hard_path( ACN_SCENE_PARAMS, const HardPath* __restrict__ recs, uint32_t 
         double a = F3_INF;
         if( ( threadIdx.x & 63 ) < got ) r = recs[ first + ( threadIdx.x & 63 ) ];
 #if ACN_POOLED
-        if constexpr( LDS ) a = root_trans_hit_pooled( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), pool, sc.matter_root, r.pixel != ACN_INVALID, r.pos, r.d, &trans, &cnt );
-        else                a = root_trans_hit_pooled( scene_view< PRUNE >( sc, sc.nodes ), pool, sc.matter_root, r.pixel != ACN_INVALID, r.pos, r.d, &trans, &cnt );
+        if constexpr( LDS ) a = root_trans_hit_pooled( scene_view< PRUNE, ACN_PARK_ORIGIN != 0 >( sc, ( LdsNodeP )acn_lds_raw ), pool, sc.matter_root, r.pixel != ACN_INVALID, r.pos, r.d, &trans, &cnt );
+        else                a = root_trans_hit_pooled( scene_view< PRUNE, ACN_PARK_ORIGIN != 0 >( sc, sc.nodes ), pool, sc.matter_root, r.pixel != ACN_INVALID, r.pos, r.d, &trans, &cnt );
 #endif
         if( r.pixel != ACN_INVALID )
         {
             ACN_LAP( PH_FETCH );
 #if !ACN_POOLED
-            if constexpr( LDS ) a = root_trans_hit( scene_view< PRUNE >( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, &trans, &cnt );
-            else                a = root_trans_hit( scene_view< PRUNE >( sc, sc.nodes ), sc.matter_root, r.pos, r.d, &trans, &cnt );
+            if constexpr( LDS ) a = root_trans_hit( scene_view< PRUNE, ACN_PARK_ORIGIN != 0 >( sc, ( LdsNodeP )acn_lds_raw ), sc.matter_root, r.pos, r.d, &trans, &cnt );
+            else                a = root_trans_hit( scene_view< PRUNE, ACN_PARK_ORIGIN != 0 >( sc, sc.nodes ), sc.matter_root, r.pos, r.d, &trans, &cnt );
 #endif
             ACN_LAP( PH_ROOT_LEAF );
             hit = a < sc.prm.max_path_length;

@@ -170,11 +170,21 @@ DEV_SIDE int obj_side_uni( SR sc, int root, bool act, V3 pos, CT* cnt )
     }
 }
 
-/* obj_ray_hit of the tree under `root` for every lane that calls (same root in all of them) */
-template< bool NOR, class SR, class CT >
-DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp, V3 rd, V3* out_nor, CT* cnt )
+/* obj_ray_hit of the tree under `root` for every lane that calls (same root in all of them).
+ * PARK: the origin of the ray the machine is evaluating lives in the lane's LDS slot (OrgLds, acn_device.h) instead of a register
+ * that the allocator would spill: written where the reference's recursion passes another origin down (scale wrappers, the walk
+ * steps of a pair) or returns to the frame's own, read where a leaf, an envelope or an in-line pair uses it. */
+template< bool NOR, bool PARK = false, class SR, class CT >
+DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp_in, V3 rd, V3* out_nor, CT* cnt )
 {
     const SceneRefT< NodeP > g = uni_view( sc );
+    OrgLds org;
+    org.p = nullptr;
+    if constexpr( PARK ) org.p = ( volatile double ACN_LDS* )( ( char ACN_LDS* )acn_lds_raw + sc.lds_stack + ACN_LDS_STACK_BYTES + ACN_LDS_POOL_BYTES ) + threadIdx.x;
+    V3 rp = rp_in;
+    auto RP = [ & ]() -> V3 { if constexpr( PARK ) return org.get(); else return rp; };
+    auto SET_RP = [ & ]( V3 v ) { if constexpr( PARK ) org.set( v ); else rp = v; };
+    if constexpr( PARK ) org.set( rp_in );
     uint32_t st_w[ ACN_CSG_MAX_DEPTH ];
     double   st_a[ ACN_CSG_MAX_DEPTH ];
     V3       st_n[ ACN_CSG_MAX_DEPTH ];     /* touched only when NOR */
@@ -186,7 +196,7 @@ DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp, V3 rd, V3* out_nor, CT* 
     uint32_t cur_w = 0;
     double cur_a = 0;                       /* pair: a1 (phase 2), walk offset (walking), result (decided) | scale: d_factor */
     V3 cur_n1 = mk( 0, 0, 0 );
-    V3 cur_rp = rp;                         /* origin of the ray the current frame received */
+    V3 cur_rp = rp_in;                      /* origin of the ray the current frame received */
     bool derived = false;                   /* wave-uniform: the rp of the next EVAL differs from cur_rp (walk steps, scale wrappers) */
     int depth = 0, na = 0;
     int node = root;
@@ -204,7 +214,7 @@ DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp, V3 rd, V3* out_nor, CT* 
         bool have = true;
         bool in = act;
         if( act ) { cnt->inc( CNT_OBJ_HIT ); ret_a = F3_INF; }
-        if( nflags & ACN_NODE_HAS_ENVELOPE ) { if( act ) in = env_ray_hits( n, rp, rd ); }
+        if( nflags & ACN_NODE_HAS_ENVELOPE ) { if( act ) in = env_ray_hits( n, RP(), rd ); }
         if( !wave_any( in ) )
         {
             /* no lane gets inside the envelope: f3_inf for all */
@@ -214,11 +224,11 @@ DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp, V3 rd, V3* out_nor, CT* 
             ACN_TALLY( 14, in );
             if( in )
             {
-                if( type == ACN_PLANE )         ret_a = plane_ray_hit( ld3( n->pos ), ld3( n->rax + 6 ), rp, rd, NOR, &ret_n );
-                else if( type == ACN_SPHERE )   ret_a = sphere_ray_hit( ld3( n->pos ), n->prm[ 0 ], rp, rd, NOR, &ret_n );
-                else if( type == ACN_SQUAROID ) ret_a = squaroid_ray_hit( n, rp, rd, NOR, &ret_n );
-                else                            { V3 dn = mk( 0, 0, 0 ); ret_a = distance_ray_hit( n, rp, rd, NOR, &dn, cnt ); if( NOR && ret_a < F3_INF ) ret_n = dn; }   /* (a real call: only dn's address escapes) */
-                if( NOR && ret_a < F3_INF && n->surface_roughness > 0 ) ret_n = roughness_normal( n, ret_n, ray_pos( rp, rd, ret_a ) );
+                if( type == ACN_PLANE )         ret_a = plane_ray_hit( ld3( n->pos ), ld3( n->rax + 6 ), RP(), rd, NOR, &ret_n );
+                else if( type == ACN_SPHERE )   ret_a = sphere_ray_hit( ld3( n->pos ), n->prm[ 0 ], RP(), rd, NOR, &ret_n );
+                else if( type == ACN_SQUAROID ) ret_a = squaroid_ray_hit( n, RP(), rd, NOR, &ret_n );
+                else                            { V3 dn = mk( 0, 0, 0 ); ret_a = distance_ray_hit( n, RP(), rd, NOR, &dn, cnt ); if( NOR && ret_a < F3_INF ) ret_n = dn; }   /* (a real call: only dn's address escapes) */
+                if( NOR && ret_a < F3_INF && n->surface_roughness > 0 ) ret_n = roughness_normal( n, ret_n, ray_pos( RP(), rd, ret_a ) );
             }
             ACN_LAP( PH_M_LEAF );
         }
@@ -231,11 +241,13 @@ DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp, V3 rd, V3* out_nor, CT* 
 #if ACN_UNI_PAIR_LEVEL >= 2
                 /* (a leaf pair through the level-2 code as well: its operands are simple, so every step is the level-1 step,
                  * and the kernel carries one expansion of the pair code instead of two) */
-                ret_a = pair_hit< 2, true >( g, n, rp, rd, NOR, &ret_n, cnt );
+                if constexpr( PARK ) ret_a = pair_hit< 2, true >( g, n, org, rd, NOR, &ret_n, cnt );
+                else                 ret_a = pair_hit< 2, true >( g, n, rp, rd, NOR, &ret_n, cnt );
 #else
-                ret_a = pair_hit< 1, true >( g, n, rp, rd, NOR, &ret_n, cnt );
+                if constexpr( PARK ) ret_a = pair_hit< 1, true >( g, n, org, rd, NOR, &ret_n, cnt );
+                else                 ret_a = pair_hit< 1, true >( g, n, rp, rd, NOR, &ret_n, cnt );
 #endif
-                if( NOR && ret_a < F3_INF && n->surface_roughness > 0 ) ret_n = roughness_normal( n, ret_n, ray_pos( rp, rd, ret_a ) );
+                if( NOR && ret_a < F3_INF && n->surface_roughness > 0 ) ret_n = roughness_normal( n, ret_n, ray_pos( RP(), rd, ret_a ) );
             }
             ACN_LAP( PH_M_PAIR );
         }
@@ -263,20 +275,20 @@ DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp, V3 rd, V3* out_nor, CT* 
             depth++;
             if( derived ) aux[ na++ ] = cur_rp;      /* na <= 2 * depth */
             cur_w = UF_PACK( node, 1, !derived ) | ( in ? UF_IN : 0u );
-            cur_rp = rp;
+            cur_rp = RP();
             derived = false;
             if( type == ACN_SCALE )   /* objects.c:1418-1428 */
             {
                 if( in ) cnt->cost( ACN_F_SCALE_WRAP );
                 M3 rax = node_rax( n );
                 V3 inv_scale = mk( n->prm[ 0 ], n->prm[ 1 ], n->prm[ 2 ] );
-                V3 p2 = v_mld( m_mlv( rax, v_sub( rp, ld3( n->pos ) ) ), inv_scale );
+                V3 p2 = v_mld( m_mlv( rax, v_sub( cur_rp, ld3( n->pos ) ) ), inv_scale );
                 V3 d2 = v_mld( m_mlv( rax, rd ), inv_scale );
                 double d_length = acn_sqrt( v_sqr( d2 ) );
                 double d_factor = ( d_length > 0 ) ? ( 1.0 / d_length ) : 0;
                 d2 = v_mlf( d2, d_factor );
                 aux[ na++ ] = rd; cur_a = d_factor;
-                rp = p2; rd = d2;
+                SET_RP( p2 ); rd = d2;
                 derived = true;
             }
             node = n->child0;
@@ -335,14 +347,14 @@ DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp, V3 rd, V3* out_nor, CT* 
                 {
                     if( fin ) { cur_a = ret_a; cur_n1 = ret_n; }
                     cur_w = UF_SET_PHASE( cur_w, 2 );
-                    node = c1; rp = cur_rp; derived = false; act = fin;
+                    node = c1; SET_RP( cur_rp ); derived = false; act = fin;
                     done = false; have = false;
                 }
                 else if( phase == 3u && wave_any( fin && UF_MODE( cur_w ) == 1u && ( cur_w & UF_SWAP ) ) )
                 {
                     /* the walking lanes whose turn was child 0 have their hit; now those whose turn is child 1 */
                     cur_w = UF_SET_PHASE( cur_w, 4 );
-                    node = c1; rp = ray_pos( cur_rp, rd, cur_a ); derived = true; act = fin && UF_MODE( cur_w ) == 1u && ( cur_w & UF_SWAP );
+                    node = c1; SET_RP( ray_pos( cur_rp, rd, cur_a ) ); derived = true; act = fin && UF_MODE( cur_w ) == 1u && ( cur_w & UF_SWAP );
                     done = false; have = false;
                 }
                 else
@@ -421,7 +433,7 @@ DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp, V3 rd, V3* out_nor, CT* 
                         const bool first0 = wave_any( w0 );
                         cur_w = UF_SET_PHASE( cur_w, first0 ? 3 : 4 );
                         node = first0 ? c0 : c1;
-                        rp = ray_pos( cur_rp, rd, cur_a ); derived = true;
+                        SET_RP( ray_pos( cur_rp, rd, cur_a ) ); derived = true;
                         act = first0 ? w0 : walking;
                         done = false; have = false;
                     }
@@ -431,8 +443,8 @@ DEV_HIT double obj_ray_hit_uni( SR sc, int root, V3 rp, V3 rd, V3* out_nor, CT* 
             if( done )
             {
                 /* POST of the composite itself (objects.c:266-282), then hand its result to its parent */
-                rp = cur_rp;
-                if( NOR && fn->surface_roughness > 0 ) { if( fin && ret_a < F3_INF ) ret_n = roughness_normal( fn, ret_n, ray_pos( rp, rd, ret_a ) ); }
+                SET_RP( cur_rp );
+                if( NOR && fn->surface_roughness > 0 ) { if( fin && ret_a < F3_INF ) ret_n = roughness_normal( fn, ret_n, ray_pos( cur_rp, rd, ret_a ) ); }
                 if( !( uw & UF_INHERIT ) ) cur_rp = aux[ --na ];
                 derived = false;
                 depth--;

@@ -865,8 +865,8 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
         size_t need = sizeof( GNode ) * ( size_t )scene->n_nodes;
         /* every machine kernel owns the stacks AND the ray pool of its workgroup (pooled_machine_hit); nodes are staged in front
          * of them only if the three fit 40 KB (four workgroups per CU) */
-        h->lds_bytes = need <= lds_max && need + ACN_LDS_STACK_BYTES + ACN_LDS_POOL_BYTES <= 40960 ? need : 0;
-        h->lds_stack_bytes = ACN_LDS_STACK_BYTES + ACN_LDS_POOL_BYTES;
+        h->lds_bytes = need <= lds_max && need + ACN_LDS_STACK_BYTES + ACN_LDS_POOL_BYTES + ACN_LDS_ORG_BYTES <= 40960 ? need : 0;
+        h->lds_stack_bytes = ACN_LDS_STACK_BYTES + ACN_LDS_POOL_BYTES + ACN_LDS_ORG_BYTES;
     }
     h->dev.flags = h->d_counts + QC_FLAGS;
     h->dev.lds_stack = h->lds_stack_bytes ? 0u : ACN_NO_LDS_STACK;   /* the kernels that own a stack area set the offset */

@@ -333,3 +333,31 @@ def test_whole_frame_matches_oracle_on_every_pixel(oracle, name, ov):
     # never by more than one step
     diff = np.abs(g8.astype(np.int16) - c8.astype(np.int16))
     assert diff.max() <= 1 and int((diff != 0).sum()) <= 8, (int(diff.max()), int((diff != 0).sum()))
+
+
+def test_cold_handle_learns_from_a_sample_and_renders_the_same_bits(oracle, monkeypatch):
+    """A cold handle renders a strided SAMPLE of the call once, throws it away and sizes its queues from the exact record counts
+    (learn_rates in actinon_hip.hip): the first frame must come out bit for bit like a later one and like a frame rendered without
+    the learning pass, no chunk may have to be redone, and the sampled pixels -- whose accumulators the learning pass touched and
+    cleared -- must equal the oracle's."""
+    sc = A.Scene.build("wine_glass", image_width=320, image_height=180, path_samples=64, direct_samples=50)
+    flat = sc.flatten()
+    pos = S.positions(flat)
+    assert len(pos) >= 16384          # large enough for the learning pass
+    h = A.Handle(flat)
+    first = h.render_positions(pos, linear=True)
+    st_first = h.last_stages()
+    second = h.render_positions(pos, linear=True)
+    st_second = h.last_stages()
+    h.close()
+    assert st_first["retries"] == 0 and st_second["retries"] == 0, (st_first, st_second)
+    assert np.array_equal(first, second)
+    monkeypatch.setenv("ACN_LEARN_SAMPLE", "0")
+    h = A.Handle(flat)
+    plain = h.render_positions(pos, linear=True)
+    h.close()
+    assert np.array_equal(first, plain)
+    stride = len(pos) // min(4096, len(pos) // 4)      # the positions the learning pass rendered and cleared
+    sample = np.arange(0, len(pos), stride)[:512]
+    cpu = oracle.render_positions(flat, pos[sample], linear=True)
+    assert np.abs(first[sample] - cpu).max() <= TOL
