@@ -152,8 +152,23 @@ struct SCEntry
     int32_t node;        /* node index (leaves: the object that is hit) */
     int32_t skip;        /* entry behind this element's subtree */
     int32_t type;        /* acn_node_type */
-    uint32_t flags;      /* ACN_NODE_HAS_ENVELOPE */
+    uint32_t flags;      /* ACN_NODE_HAS_ENVELOPE | ACN_SC_SPHERE ( skip = index into sc_spheres ) | ACN_SC_ROUGH */
 };
+#define ACN_SC_SPHERE 0x10000u
+#define ACN_SC_ROUGH  0x20000u
+#define ACN_SC_BOUNDING 0x40000u   /* the upload step has verified that the envelope contains every leaf below the entry (all of them spheres) */
+#ifndef ACN_SC_CULL
+#define ACN_SC_CULL 1
+#endif
+#ifndef ACN_SC_EARLY_NEXT
+#define ACN_SC_EARLY_NEXT 0
+#endif
+#ifndef ACN_SC_DEFER
+#define ACN_SC_DEFER 0
+#endif
+#ifndef ACN_SC_SPHERE_TABLE
+#define ACN_SC_SPHERE_TABLE 1
+#endif
 
 /* device-resident scene, parameterised by where the node array is read from */
 template< class NP >
@@ -175,6 +190,7 @@ struct DevSceneT
     uint32_t prune_base; /* elems[ prune_base + node ]: offset of the node's prune program in elems[], or -1 */
     uint32_t class0_min; /* shading tasks with more samples than this run on 64 lanes (ACN_CLASS0_MIN, acn_pipeline.h: size_class) */
     const SCEntry* sc_table;   /* pre-order tables of the simple compounds */
+    const double* sc_spheres;  /* ( pos, radius ) of the sphere leaves of those tables, see SCEntry.flags */
     CDblP env_tab;             /* per entry of elems[ 0 .. 2 n_elems ): envelope centre and radius of that element ( radius < 0: none ), see root_candidates */
     static constexpr bool prune = false;
     static constexpr bool park = false;   /* the lock-step machines keep the ray origin in LDS (OrgLds): only where the kernel owns the slot */
@@ -192,7 +208,7 @@ __device__ __forceinline__ DevSceneT< NP2 > scene_rebind( const DevScene& sc, NP
     DevSceneT< NP2 > r;
     r.nodes = nodes; r.gnodes = sc.nodes; r.mats = sc.mats; r.elems = sc.elems; r.textures = sc.textures;
     r.light_root = sc.light_root; r.matter_root = sc.matter_root; r.n_nodes = sc.n_nodes; r.n_elems = sc.n_elems;
-    r.prm = sc.prm; r.camera_rotation = sc.camera_rotation; r.unit_f = sc.unit_f; r.flags = sc.flags; r.lds_stack = sc.lds_stack; r.prune_base = sc.prune_base; r.class0_min = sc.class0_min; r.sc_table = sc.sc_table; r.env_tab = sc.env_tab;
+    r.prm = sc.prm; r.camera_rotation = sc.camera_rotation; r.unit_f = sc.unit_f; r.flags = sc.flags; r.lds_stack = sc.lds_stack; r.prune_base = sc.prune_base; r.class0_min = sc.class0_min; r.sc_table = sc.sc_table; r.sc_spheres = sc.sc_spheres; r.env_tab = sc.env_tab;
     return r;
 }
 
@@ -221,6 +237,7 @@ enum
 template< bool ON > struct Cnt;
 template<> struct Cnt< true >
 {
+    static constexpr bool counting = true;
     unsigned c[ CNT_N ];
     unsigned long long flop;   /* sum of event costs, acn_costs.h */
     unsigned transc;           /* transcendental calls */
@@ -231,6 +248,7 @@ template<> struct Cnt< true >
 };
 template<> struct Cnt< false >
 {
+    static constexpr bool counting = false;
     __device__ __forceinline__ void clear() {}
     __device__ __forceinline__ void inc( int ) {}
     __device__ __forceinline__ void add( int, unsigned ) {}
@@ -1383,6 +1401,20 @@ DEVN double compound_ray_hit_dev( SR sc, int cmp, V3 rp, V3 rd, bool want_nor, V
     return min_a;
 }
 
+/* true only if every point of the sphere ( env_pos, r ) on the ray lies beyond ray parameter `bound` by a margin that covers
+ * the F3_EPS the hit routines subtract and all rounding: the origin is outside the sphere, the sphere lies ahead, and its entry
+ * point -s - sqrt( s*s - q ) exceeds bound + margin.  Only called for envelopes the ray hits ( s*s >= q ).  Conservative: a `false`
+ * costs a visit, a wrong `true` would cost a hit. */
+DEV bool env_behind( V3 env_pos, double r, V3 rp, V3 rd, double bound )
+{
+    V3 p = v_sub( rp, env_pos );
+    double s = v_mlv( p, rd );
+    double q = v_sqr( p ) - ( r * r );
+    double s2 = s * s;
+    double u = ( -s - bound ) - ( 1E-5 + 1E-9 * ( fabs( s ) + fabs( bound ) ) );
+    return q > 0 && u > 0 && u * u > ( s2 - q ) + 1E-9 * ( s2 + fabs( q ) );
+}
+
 /* Simple compounds: a root element that is a compound whose whole subtree consists of nested compounds and simple
  * leaves (many_spheres: 32 768 spheres under five levels of enveloped compounds).  The upload step lays its subtree
  * out in pre-order as SCEntry records with a skip link per entry (elems[ offset ], elems[ offset + 1 ]: first entry and
@@ -1398,46 +1430,109 @@ DEV double simple_compound_hit( const SC& sc, int cmp, V3 rp, V3 rd, V3* p_nor, 
     int i = sc.elems[ off ], end = i + sc.elems[ off + 1 ];
     double min_a = F3_INF;
     if( i >= end ) return min_a;
-    /* Every visit is a load the next one depends on (the entry decides where the walk goes).  ACN_SC_PREFETCH requests the
-     * entry behind the current one before the current one is tested (a visit advances by ONE entry except where an enveloped
-     * compound is missed).  Measured and OFF: many_spheres p256, every 16th pixel of the 1080p frame, 1 577 ms without, 1 864 ms
-     * with (profiles/r04/ab_c3_prefetch.txt): half of the visits of a ray miss an enveloped compound and jump, so half of the
-     * prefetched 48 bytes are thrown away, and the walk is short of L2 bandwidth per lane, not of requests in flight. */
+    /* The walk does not depend on what the leaves return (an envelope test is a predicate of the ray alone; only the occlusion
+     * form leaves early), and k_shade<64> on many_spheres is short of VALU issue slots, not of memory (PMC, profiles/r04/NOTES.md
+     * section 6: 72 % of the issue slots busy, waves waiting 20 % of their time): one lane in fifty stands on a leaf whose envelope
+     * its ray hits, so three wave iterations in four ran the whole sphere routine for one or two lanes.  DEFER: a lane that finds
+     * such a leaf parks it (one slot) and walks on; only when a lane of the wave finds a SECOND one do all lanes evaluate what they
+     * have parked, behind a wave-uniform branch.  Leaves are evaluated in walk order per lane, so min_a, the strict `<` tie rule
+     * and the first leaf within `limit` are the ones of the plain loop; the occlusion form may walk a few entries further before
+     * it learns that it could have left.  A hit sphere's normal is computed once, behind the loop, from the same expression.
+     * The counting kernels keep the plain loop: their event counts are compared with the oracle's. */
+    constexpr bool DEFER = ACN_SC_DEFER && !CT::counting;
+    /* CULL: an entry whose envelope provably contains everything below it (ACN_SC_BOUNDING) and lies wholly behind the best hit so
+     * far cannot change the result -- every hit in it is farther, and a farther hit never replaces a nearer one -- so it is treated
+     * like a missed envelope.  The reference visits it (compound.c:215-243 has no such test); the counting kernels therefore do,
+     * too.  many_spheres, every 16th pixel: see profiles/r04/NOTES.md section 6. */
+    constexpr bool CULL = ACN_SC_CULL && !CT::counting;
+    uint32_t pend_flags = 0; int pend_node = -1, pend_sph = 0;   /* the parked leaf ( flags != 0: one is parked ) */
+    int best_sph = -1; uint32_t best_flags = 0;                   /* DEFER && NOR: the sphere min_a belongs to */
+    auto leaf = [ & ]( int node, int sph, uint32_t flags ) -> bool   /* true: the occlusion form is done */
+    {
+        V3 nor = mk( 0, 0, 0 );
+        double a;
+        bool table = false;
+#if ACN_SC_SPHERE_TABLE
+        if( flags & ACN_SC_SPHERE )   /* the sphere itself from the compact table beside the entries (32 B, L2-resident) instead of its 192-byte node */
+        {
+            const double* g = sc.sc_spheres + 4 * ( size_t )sph;
+            a = sphere_ray_hit( mk( g[ 0 ], g[ 1 ], g[ 2 ] ), g[ 3 ], rp, rd, NOR && !DEFER, &nor );
+            if( NOR && !DEFER && a < F3_INF && ( flags & ACN_SC_ROUGH ) ) nor = roughness_normal( &sc.nodes[ node ], nor, ray_pos( rp, rd, a ) );
+            table = true;
+        }
+        else
+#endif
+        a = simple_leaf_hit( &sc.nodes[ node ], rp, rd, NOR, &nor );
+        if( a < min_a )
+        {
+            min_a = a;
+            if( NOR ) *p_nor = nor;
+            if( NOR && DEFER ) { best_sph = table ? sph : -1; best_flags = flags; }
+            *hit_obj = node;
+            if( a <= limit ) return true;
+        }
+        return false;
+    };
     SCEntry e = sc.sc_table[ i ];
     while( i < end )
     {
 #ifdef ACN_SC_PREFETCH
         const SCEntry ahead = sc.sc_table[ i + 1 < end ? i + 1 : i ];
 #endif
-        const bool miss = ( e.flags & ACN_NODE_HAS_ENVELOPE ) && !env_ray_hits_raw( ld3( e.env_pos ), e.env_radius, rp, rd, cnt );
-        int next = i + 1;
-        if( e.type == ACN_COMPOUND )
+        bool miss = ( e.flags & ACN_NODE_HAS_ENVELOPE ) && !env_ray_hits_raw( ld3( e.env_pos ), e.env_radius, rp, rd, cnt );
+        if( CULL && !miss && ( e.flags & ACN_SC_BOUNDING ) )
         {
-            if( miss ) next = e.skip;
+            const double bound = NOR ? min_a : limit;   /* the occlusion form leaves at the first hit within `limit`: nothing beyond it matters */
+            if( bound < F3_INF ) miss = env_behind( ld3( e.env_pos ), e.env_radius, rp, rd, bound );
         }
-        else
+        const bool is_leaf = e.type != ACN_COMPOUND;
+        const int next = ( !is_leaf && miss ) ? e.skip : i + 1;
+#if ACN_SC_EARLY_NEXT
+        /* the next entry requested BEFORE the leaf is evaluated.  Measured (profiles/r04/ab_c3_table_s20.txt): -4 % alone, +5 % on top
+         * of the sphere table: off */
+        SCEntry e_next = e;
+        if( next < end ) e_next = sc.sc_table[ next ];
+#endif
+        if( is_leaf ) cnt->inc( CNT_OBJ_HIT );
+        const bool want = is_leaf && !miss;
+        if( DEFER )
         {
-            cnt->inc( CNT_OBJ_HIT );
-            if( !miss )
+            if( __ballot( want && pend_flags != 0 ) != 0 )
             {
-                V3 nor = mk( 0, 0, 0 );
-                double a = simple_leaf_hit( &sc.nodes[ e.node ], rp, rd, NOR, &nor );
-                if( a < min_a )
+                if( pend_flags != 0 )
                 {
-                    min_a = a;
-                    if( NOR ) *p_nor = nor;
-                    *hit_obj = e.node;
-                    if( a <= limit ) return a;
+                    if( leaf( pend_node, pend_sph, pend_flags ) ) return min_a;
+                    pend_flags = 0;
                 }
             }
+            if( want ) { pend_node = e.node; pend_sph = e.skip; pend_flags = e.flags | 0x80000000u; }
         }
-#ifdef ACN_SC_PREFETCH
+        else if( want )
+        {
+            if( leaf( e.node, e.skip, e.flags ) ) return min_a;
+        }
+#if ACN_SC_EARLY_NEXT
+        e = e_next;
+#elif defined( ACN_SC_PREFETCH )
         if( next == i + 1 ) e = ahead;
         else if( next < end ) e = sc.sc_table[ next ];
 #else
         if( next < end ) e = sc.sc_table[ next ];
 #endif
         i = next;
+    }
+    if( DEFER )
+    {
+        if( pend_flags != 0 && leaf( pend_node, pend_sph, pend_flags ) ) return min_a;
+#if ACN_SC_SPHERE_TABLE
+        if( NOR && best_sph >= 0 )   /* sphere_ray_hit's normal (gmath.h:64-83), once, for the hit that won */
+        {
+            const double* g = sc.sc_spheres + 4 * ( size_t )best_sph;
+            V3 nor = v_of_length( v_sub( ray_pos( rp, rd, min_a ), mk( g[ 0 ], g[ 1 ], g[ 2 ] ) ), 1.0 );
+            if( best_flags & ACN_SC_ROUGH ) nor = roughness_normal( &sc.nodes[ *hit_obj ], nor, ray_pos( rp, rd, min_a ) );
+            *p_nor = nor;
+        }
+#endif
     }
     return min_a;
 }

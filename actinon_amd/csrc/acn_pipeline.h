@@ -195,7 +195,9 @@ DEV int size_class( uint64_t n, uint32_t class0_min )
  * consumers skip dead slots.  The state ( next free slot, end ) of a wave's reservation lives in LDS, one pair per
  * wave and queue, and is touched by one lane per append -- which makes appends legal under divergent control flow
  * (the sample loops of k_shade): the lanes that reach an append together form its ballot. */
+#ifndef ACN_QCHUNK
 #define ACN_QCHUNK 64
+#endif
 /* spare: a second reservation taken ahead of need (chunk_prefetch), ACN_INVALID if none */
 struct ChunkState { uint32_t cur, end, spare, pad; };
 typedef ChunkState ACN_LDS* ChunkP;

@@ -172,6 +172,7 @@ struct acn_scene_handle
     int32_t* d_elems = nullptr;
     acn_texture* d_textures = nullptr;
     SCEntry* d_sc_table = nullptr;
+    double* d_sc_spheres = nullptr;            /* ( pos, radius ) of the sphere leaves of d_sc_table */
     double* d_env_tab = nullptr;               /* envelopes of the compound slices, element by element (acn_device.h: root_candidates) */
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;         /* the direct-light half of a fissioned level and its deferred shadow rays (render_chunk) */
@@ -597,6 +598,7 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
      * keep the given order because ties go to the first element, compound.c:225-243) */
     std::vector< int32_t > elems2( 2 * ( size_t )scene->n_elems + 1, 0 );
     std::vector< SCEntry > sc_table;   /* pre-order tables of the simple compounds (acn_device.h: simple_compound_hit) */
+    std::vector< double > sc_spheres;
     {
         std::vector< double > cost( scene->n_nodes, -1.0 );
         std::function< double( int32_t ) > node_cost = [ & ]( int32_t i ) -> double
@@ -761,6 +763,8 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
                 simple[ i ] = ok ? 1 : 0;
                 return ok;
             };
+            const bool no_cull = getenv( "ACN_NO_SC_CULL" ) != nullptr;
+            size_t n_bounding = 0;
             std::function< void( int32_t ) > emit = [ & ]( int32_t c )   /* children of compound c, depth first */
             {
                 const acn_node& a = scene->nodes[ c ];
@@ -775,6 +779,27 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
                     sct.push_back( rec );
                     if( en.type == ACN_COMPOUND ) emit( e );
                     sct[ at ].skip = ( int32_t )sct.size();   /* the entry behind e's subtree */
+                    if( ( rec.flags & ACN_NODE_HAS_ENVELOPE ) && !no_cull )   /* does the envelope contain every leaf below? (simple_compound_hit: CULL) */
+                    {
+                        bool inside = true;
+                        for( size_t k = at; k < sct.size() && inside; k++ )
+                        {
+                            const acn_node& ln = scene->nodes[ sct[ k ].node ];
+                            if( ln.type == ACN_COMPOUND ) continue;
+                            if( ln.type != ACN_SPHERE ) { inside = false; break; }
+                            double d2 = 0;
+                            for( int c = 0; c < 3; c++ ) d2 += ( ln.pos[ c ] - en.env_pos[ c ] ) * ( ln.pos[ c ] - en.env_pos[ c ] );
+                            inside = sqrt( d2 ) + fabs( ln.prm[ 0 ] ) <= fabs( en.env_radius ) * ( 1.0 - 1E-9 );
+                        }
+                        if( inside ) { sct[ at ].flags |= ACN_SC_BOUNDING; n_bounding++; }
+                    }
+                    if( en.type == ACN_SPHERE )   /* a leaf never follows its link: it names the sphere's record instead */
+                    {
+                        sct[ at ].skip = ( int32_t )( sc_spheres.size() / 4 );
+                        sct[ at ].flags |= ACN_SC_SPHERE | ( en.surface_roughness > 0 ? ACN_SC_ROUGH : 0u );
+                        for( int c = 0; c < 3; c++ ) sc_spheres.push_back( en.pos[ c ] );
+                        sc_spheres.push_back( en.prm[ 0 ] );
+                    }
                 }
             };
             for( int root : { scene->light_root, scene->matter_root } )
@@ -793,6 +818,7 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
                     h->prune = true;   /* the extras kernel variants */
                 }
             }
+            if( getenv( "ACN_VERBOSE" ) && sct.size() ) fprintf( stderr, "actinon_hip: simple compounds: %zu entries, %zu with a verified bounding envelope\n", sct.size(), n_bounding );
         }
         elems2.push_back( 0 );
     }
@@ -801,6 +827,9 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     HIP_TRY_H( hipMalloc( &h->d_sc_table, sizeof( SCEntry ) * ( sc_table.size() ? sc_table.size() : 1 ) ) );
     if( sc_table.size() ) HIP_TRY_H( hipMemcpy( h->d_sc_table, sc_table.data(), sizeof( SCEntry ) * sc_table.size(), hipMemcpyHostToDevice ) );
     h->dev.sc_table = h->d_sc_table;
+    HIP_TRY_H( hipMalloc( &h->d_sc_spheres, sizeof( double ) * ( sc_spheres.size() ? sc_spheres.size() : 4 ) ) );
+    if( sc_spheres.size() ) HIP_TRY_H( hipMemcpy( h->d_sc_spheres, sc_spheres.data(), sizeof( double ) * sc_spheres.size(), hipMemcpyHostToDevice ) );
+    h->dev.sc_spheres = h->d_sc_spheres;
     HIP_TRY_H( hipMalloc( &h->d_env_tab, sizeof( double ) * env_tab.size() ) );
     HIP_TRY_H( hipMemcpy( h->d_env_tab, env_tab.data(), sizeof( double ) * env_tab.size(), hipMemcpyHostToDevice ) );
     h->dev.env_tab = ( CDblP )h->d_env_tab;
@@ -921,6 +950,7 @@ extern "C" void acn_scene_free( acn_scene_handle* h )
         if( h->d_elems ) hipFree( h->d_elems );
         if( h->d_textures ) hipFree( h->d_textures );
         if( h->d_sc_table ) hipFree( h->d_sc_table );
+        if( h->d_sc_spheres ) hipFree( h->d_sc_spheres );
         if( h->d_env_tab ) hipFree( h->d_env_tab );
     }
     if( h->d_counters ) hipFree( h->d_counters );
@@ -1406,7 +1436,7 @@ static int learn_rates( acn_scene_handle* h, const double* d_pos_xy, size_t firs
          * tasks, specular rays and probes are appended by k_shade_hits and ~4 walk passes, path-sample hits and the two deferred
          * queues by the four k_shade launches (and k_hard_path). */
         {
-            const double per_launch = 64.0 * 4.0 * ( double )plan_grid;
+            const double per_launch = ( double )ACN_QCHUNK * 4.0 * ( double )plan_grid;
             const double walkers = 3.0 * per_launch, shaders = 3.0 * per_launch;   /* (not every wave of every launch leaves a full reservation behind) */
             const double dead[ WQ_N ] = { walkers, shaders, walkers + shaders, shaders, walkers };
             const double pp = ( double )( plan_positions < ACN_CHUNK_TARGET ? plan_positions : ACN_CHUNK_TARGET );
