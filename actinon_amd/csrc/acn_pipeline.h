@@ -198,8 +198,11 @@ DEV int size_class( uint64_t n, uint32_t class0_min )
 #ifndef ACN_QCHUNK
 #define ACN_QCHUNK 64
 #endif
+#ifndef ACN_QCHUNK_MAX
+#define ACN_QCHUNK_MAX 512u
+#endif
 /* spare: a second reservation taken ahead of need (chunk_prefetch), ACN_INVALID if none */
-struct ChunkState { uint32_t cur, end, spare, pad; };
+struct ChunkState { uint32_t cur, end, spare, size; };   /* size: slots per reservation (ACN_QCHUNK unless the kernel knows better, see chunks_resize) */
 typedef ChunkState ACN_LDS* ChunkP;
 #define ACN_NCHUNKS 8     /* reservation states per wave */
 /* LDS block of the reservation states of a 256-lane workgroup; 256 B keeps the dynamic LDS behind it 16-byte aligned */
@@ -215,7 +218,20 @@ DEV uint32_t lanes_below( unsigned long long mask )
 
 DEV void chunks_init( ChunkP cs )
 {
-    if( ( threadIdx.x & 63 ) < ACN_NCHUNKS ) { cs[ threadIdx.x & 63 ].cur = 0; cs[ threadIdx.x & 63 ].end = 0; cs[ threadIdx.x & 63 ].spare = ACN_INVALID_SLOT; }
+    if( ( threadIdx.x & 63 ) < ACN_NCHUNKS ) { cs[ threadIdx.x & 63 ].cur = 0; cs[ threadIdx.x & 63 ].end = 0; cs[ threadIdx.x & 63 ].spare = ACN_INVALID_SLOT; cs[ threadIdx.x & 63 ].size = ACN_QCHUNK; }
+}
+/* Larger reservations for a wave that is going to append a lot.  Every reservation is one returning atomic on the queue's ONE
+ * counter, and the device serves same-address atomics of a launch one after the other: k_shade_hits on many_spheres turns 2.7e8
+ * path hits per frame (every 16th pixel) into as many tasks, one reservation per wave and batch of 64 -- and spent 152 ms doing it
+ * with 4 % of its VALU slots busy; with 256 slots per reservation 64 ms (profiles/r04/ab_qchunk_s24.txt).  The price of a large
+ * reservation is its unused tail (dead slots the consumers step over: a fixed 256 costs the wine glass 4 - 18 %), so the size
+ * follows what the wave expects to append: an eighth of its share of the input, 64 ... 512. */
+DEV void chunks_resize( ChunkP cs, uint32_t items_of_launch )
+{
+    const uint32_t per_wave = items_of_launch / ( gridDim.x * 4u );
+    uint32_t size = ( per_wave / 8u ) & ~63u;
+    size = size < ( uint32_t )ACN_QCHUNK ? ( uint32_t )ACN_QCHUNK : size > ACN_QCHUNK_MAX ? ACN_QCHUNK_MAX : size;
+    if( ( threadIdx.x & 63 ) < ACN_NCHUNKS ) cs[ threadIdx.x & 63 ].size = size;
 }
 
 /* Reservations ahead of need.  A k_walk wave appends up to 64 records per step to each of its queues, so nearly every
@@ -235,7 +251,7 @@ DEV void chunk_prefetch_issue( ChunkP cs, uint32_t* counter, bool enabled, Chunk
     enabled = false;
 #endif
     pf.issued = enabled && end != 0u && end - cur < 64u && spare == ACN_INVALID_SLOT;
-    if( pf.issued ) pf.base = atomicAdd( counter, ( uint32_t )ACN_QCHUNK );
+    if( pf.issued ) pf.base = atomicAdd( counter, cs->size );
 }
 DEV void chunk_prefetch_park( ChunkP cs, const ChunkPrefetch& pf )
 {
@@ -258,10 +274,10 @@ DEV uint32_t chunk_alloc( ChunkP cs, uint32_t* counter, bool want )
         base = cur; room = end - cur;
         if( m > room )
         {
-            const uint32_t spare = cs->spare;
+            const uint32_t spare = cs->spare, size = cs->size;
             if( spare != ACN_INVALID_SLOT ) { base2 = spare; cs->spare = ACN_INVALID_SLOT; }
-            else base2 = atomicAdd( counter, ( uint32_t )ACN_QCHUNK );
-            cs->end = base2 + ACN_QCHUNK;
+            else base2 = atomicAdd( counter, size );
+            cs->end = base2 + size;
             cs->cur = base2 + ( m - room );
         }
         else cs->cur = cur + m;
@@ -276,10 +292,10 @@ DEV uint32_t chunk_alloc( ChunkP cs, uint32_t* counter, bool want )
 template< class KILL >
 DEV void chunk_close( ChunkP cs, uint32_t cap, KILL kill, uint32_t* dead = nullptr )
 {
-    uint32_t cur = cs->cur, end = cs->end, spare = cs->spare;
+    uint32_t cur = cs->cur, end = cs->end, spare = cs->spare, size = cs->size;
     for( uint32_t k = cur + ( threadIdx.x & 63 ); k < end; k += 64 ) if( k < cap ) kill( k );
-    if( spare != ACN_INVALID_SLOT ) for( uint32_t k = spare + ( threadIdx.x & 63 ); k < spare + ACN_QCHUNK; k += 64 ) if( k < cap ) kill( k );
-    const uint32_t d = end - cur + ( spare != ACN_INVALID_SLOT ? ( uint32_t )ACN_QCHUNK : 0u );
+    if( spare != ACN_INVALID_SLOT ) for( uint32_t k = spare + ( threadIdx.x & 63 ); k < spare + size; k += 64 ) if( k < cap ) kill( k );
+    const uint32_t d = end - cur + ( spare != ACN_INVALID_SLOT ? size : 0u );
     if( dead && d && ( threadIdx.x & 63 ) == 0 ) atomicAdd( dead, d );
 }
 
@@ -910,6 +926,7 @@ void k_shade_hits( ACN_SCENE_PARAMS, ACN_TASKQ_PARAMS, const HitRec* __restrict_
     ACN_TASKQ_VIEW
     const ChunkP cs = ACN_CHUNKS_OF_WAVE;
     chunks_init( cs );
+    chunks_resize( cs, n );
     Cnt< COUNT > cnt;
     cnt.clear();
     RayQ rq;
