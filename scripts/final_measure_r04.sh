@@ -53,7 +53,7 @@ find $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE -name "*.csv" -size +20M -delete
 timeout -k 10 600 python bench.py --steps 10 --warmup 2 --checksum $out/checksum_wine_glass_1080p.json > $out/bench_wine_glass_1080p.json 2> $out/bench.err || { tail -n 5 $out/bench.err; exit 1; }
 cut -c1-200 $out/bench_wine_glass_1080p.json
 for split in tiles samples; do
-  ACN_BENCH_SINGLE_DEVICE=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --split $split > $out/bench_2ranks_rehearsal_$split.json 2> $out/bench_2ranks_$split.err || { tail -n 5 $out/bench_2ranks_$split.err; exit 1; }
+  ACN_BENCH_SINGLE_DEVICE=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 3 --no-cpu-baseline --split $split > $out/bench_2ranks_rehearsal_$split.json 2> $out/bench_2ranks_$split.err || { tail -n 5 $out/bench_2ranks_$split.err; exit 1; }
   grep '^{' $out/bench_2ranks_rehearsal_$split.json | cut -c1-200
 done
 # steadiness: consecutive frames of the two lamp scenes, this tree and the round-2 tree (if it travelled) on the same box
