@@ -160,6 +160,9 @@ struct SCEntry
 #ifndef ACN_SC_CULL
 #define ACN_SC_CULL 1
 #endif
+#ifndef ACN_SC_TWO_ORDERS
+#define ACN_SC_TWO_ORDERS 1
+#endif
 #ifndef ACN_SC_EARLY_NEXT
 #define ACN_SC_EARLY_NEXT 0
 #endif
@@ -1427,9 +1430,27 @@ template< bool NOR, class SC, class CT >
 DEV double simple_compound_hit( const SC& sc, int cmp, V3 rp, V3 rd, V3* p_nor, int* hit_obj, double limit, CT* cnt )
 {
     int off = sc.elems[ sc.prune_base + ( uint32_t )cmp ];
-    int i = sc.elems[ off ], end = i + sc.elems[ off + 1 ];
+    int i = sc.elems[ off ];
+    const int count = sc.elems[ off + 1 ];
     double min_a = F3_INF;
-    if( i >= end ) return min_a;
+    if( count <= 0 ) return min_a;
+    /* The result is the minimum over the leaves, the FIRST leaf in the reference's order winning a tie -- it does not depend on the
+     * order of the walk as long as that rule is kept.  The upload step lays big subtrees out a second time with the children of
+     * every compound in reverse order; a ray that runs against the order of the first table (order_dir: the direction along which
+     * later children lie, summed over the subtree's compounds) walks the second, meets its near leaves sooner and culls more.  In
+     * the reversed table the leaves come in exactly the reverse order, so "first wins" becomes "last visited wins": `<=`. */
+    bool rev = false;
+    if( ACN_SC_CULL && ACN_SC_TWO_ORDERS && !CT::counting )
+    {
+        const int first_rev = sc.elems[ off + 2 ];
+        if( first_rev >= 0 )
+        {
+            const double* g = sc.sc_spheres + 4 * ( size_t )sc.elems[ off + 3 ];
+            rev = v_mlv( rd, mk( g[ 0 ], g[ 1 ], g[ 2 ] ) ) < 0;
+            if( rev ) i = first_rev;
+        }
+    }
+    const int end = i + count;
     /* The walk does not depend on what the leaves return (an envelope test is a predicate of the ray alone; only the occlusion
      * form leaves early), and k_shade<64> on many_spheres is short of VALU issue slots, not of memory (PMC, profiles/r04/NOTES.md
      * section 6: 72 % of the issue slots busy, waves waiting 20 % of their time): one lane in fifty stands on a leaf whose envelope
@@ -1463,7 +1484,7 @@ DEV double simple_compound_hit( const SC& sc, int cmp, V3 rp, V3 rd, V3* p_nor, 
         else
 #endif
         a = simple_leaf_hit( &sc.nodes[ node ], rp, rd, NOR, &nor );
-        if( a < min_a )
+        if( rev ? ( a <= min_a && a < F3_INF ) : ( a < min_a ) )
         {
             min_a = a;
             if( NOR ) *p_nor = nor;

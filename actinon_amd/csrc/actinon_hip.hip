@@ -764,12 +764,25 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
                 return ok;
             };
             const bool no_cull = getenv( "ACN_NO_SC_CULL" ) != nullptr;
-            size_t n_bounding = 0;
-            std::function< void( int32_t ) > emit = [ & ]( int32_t c )   /* children of compound c, depth first */
+            size_t n_bounding = 0, n_reversed = 0;
+            const bool no_rev = getenv( "ACN_NO_SC_REVERSED" ) != nullptr;
+            std::vector< int32_t > sph_of( scene->n_nodes, -1 );      /* sphere record of a leaf, flags of an entry: the reversed table reuses them */
+            std::vector< uint32_t > flags_of( scene->n_nodes, 0u );
+            double order_dir[ 3 ] = { 0, 0, 0 };                      /* along which the children of the compounds at hand come later, summed over the compounds */
+            auto centre = [ & ]( const acn_node& x, int c ) { return ( x.flags & ACN_NODE_HAS_ENVELOPE ) ? x.env_pos[ c ] : x.pos[ c ]; };
+            std::function< void( int32_t, bool ) > emit = [ & ]( int32_t c, bool reversed )   /* children of compound c, depth first */
             {
                 const acn_node& a = scene->nodes[ c ];
-                for( int32_t k = 0; k < a.child1; k++ )
+                if( !reversed && a.child1 > 1 )
                 {
+                    double mean[ 3 ] = { 0, 0, 0 };
+                    for( int32_t k = 0; k < a.child1; k++ ) for( int x = 0; x < 3; x++ ) mean[ x ] += centre( scene->nodes[ scene->elems[ a.child0 + k ] ], x ) / a.child1;
+                    for( int32_t k = 0; k < a.child1; k++ ) for( int x = 0; x < 3; x++ )
+                        order_dir[ x ] += ( k - 0.5 * ( a.child1 - 1 ) ) * ( centre( scene->nodes[ scene->elems[ a.child0 + k ] ], x ) - mean[ x ] );
+                }
+                for( int32_t kk = 0; kk < a.child1; kk++ )
+                {
+                    const int32_t k = reversed ? a.child1 - 1 - kk : kk;
                     int32_t e = scene->elems[ a.child0 + k ];
                     const acn_node& en = scene->nodes[ e ];
                     size_t at = sct.size();
@@ -777,29 +790,37 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
                     memcpy( rec.env_pos, en.env_pos, sizeof( rec.env_pos ) );
                     rec.env_radius = en.env_radius; rec.node = e; rec.skip = 0; rec.type = en.type; rec.flags = en.flags & ACN_NODE_HAS_ENVELOPE;
                     sct.push_back( rec );
-                    if( en.type == ACN_COMPOUND ) emit( e );
+                    if( en.type == ACN_COMPOUND ) emit( e, reversed );
                     sct[ at ].skip = ( int32_t )sct.size();   /* the entry behind e's subtree */
+                    if( reversed )
+                    {
+                        sct[ at ].flags = flags_of[ e ];
+                        if( en.type == ACN_SPHERE ) sct[ at ].skip = sph_of[ e ];
+                        continue;
+                    }
                     if( ( rec.flags & ACN_NODE_HAS_ENVELOPE ) && !no_cull )   /* does the envelope contain every leaf below? (simple_compound_hit: CULL) */
                     {
                         bool inside = true;
-                        for( size_t k = at; k < sct.size() && inside; k++ )
+                        for( size_t j = at; j < sct.size() && inside; j++ )
                         {
-                            const acn_node& ln = scene->nodes[ sct[ k ].node ];
+                            const acn_node& ln = scene->nodes[ sct[ j ].node ];
                             if( ln.type == ACN_COMPOUND ) continue;
                             if( ln.type != ACN_SPHERE ) { inside = false; break; }
                             double d2 = 0;
-                            for( int c = 0; c < 3; c++ ) d2 += ( ln.pos[ c ] - en.env_pos[ c ] ) * ( ln.pos[ c ] - en.env_pos[ c ] );
+                            for( int x = 0; x < 3; x++ ) d2 += ( ln.pos[ x ] - en.env_pos[ x ] ) * ( ln.pos[ x ] - en.env_pos[ x ] );
                             inside = sqrt( d2 ) + fabs( ln.prm[ 0 ] ) <= fabs( en.env_radius ) * ( 1.0 - 1E-9 );
                         }
                         if( inside ) { sct[ at ].flags |= ACN_SC_BOUNDING; n_bounding++; }
                     }
                     if( en.type == ACN_SPHERE )   /* a leaf never follows its link: it names the sphere's record instead */
                     {
-                        sct[ at ].skip = ( int32_t )( sc_spheres.size() / 4 );
+                        sph_of[ e ] = ( int32_t )( sc_spheres.size() / 4 );
+                        sct[ at ].skip = sph_of[ e ];
                         sct[ at ].flags |= ACN_SC_SPHERE | ( en.surface_roughness > 0 ? ACN_SC_ROUGH : 0u );
-                        for( int c = 0; c < 3; c++ ) sc_spheres.push_back( en.pos[ c ] );
+                        for( int x = 0; x < 3; x++ ) sc_spheres.push_back( en.pos[ x ] );
                         sc_spheres.push_back( en.prm[ 0 ] );
                     }
+                    flags_of[ e ] = sct[ at ].flags;
                 }
             };
             for( int root : { scene->light_root, scene->matter_root } )
@@ -812,13 +833,28 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
                     elems2[ h->dev.prune_base + e ] = ( int32_t )elems2.size();
                     elems2.push_back( ( int32_t )sct.size() );     /* first entry */
                     size_t first = sct.size();
-                    emit( e );
-                    elems2.push_back( ( int32_t )( sct.size() - first ) );   /* entry count */
+                    order_dir[ 0 ] = order_dir[ 1 ] = order_dir[ 2 ] = 0;
+                    emit( e, false );
+                    const size_t count = sct.size() - first;
+                    elems2.push_back( ( int32_t )count );          /* entry count */
+                    /* the same subtree with the children of every compound in reverse order, for rays that run against the order of the
+                     * first (simple_compound_hit: the walk culls more the sooner it meets the near leaves); -1: none */
+                    const double len = sqrt( order_dir[ 0 ] * order_dir[ 0 ] + order_dir[ 1 ] * order_dir[ 1 ] + order_dir[ 2 ] * order_dir[ 2 ] );
+                    if( !no_rev && !no_cull && count >= 64 && len > 0 )
+                    {
+                        elems2.push_back( ( int32_t )sct.size() );
+                        elems2.push_back( ( int32_t )( sc_spheres.size() / 4 ) );
+                        for( int x = 0; x < 3; x++ ) sc_spheres.push_back( order_dir[ x ] / len );
+                        sc_spheres.push_back( 0.0 );
+                        emit( e, true );
+                        n_reversed += count;
+                    }
+                    else { elems2.push_back( -1 ); elems2.push_back( 0 ); }
                     nodes[ e ].flags |= ACN_GFLAG_SIMPLE_COMPOUND;
                     h->prune = true;   /* the extras kernel variants */
                 }
             }
-            if( getenv( "ACN_VERBOSE" ) && sct.size() ) fprintf( stderr, "actinon_hip: simple compounds: %zu entries, %zu with a verified bounding envelope\n", sct.size(), n_bounding );
+            if( getenv( "ACN_VERBOSE" ) && sct.size() ) fprintf( stderr, "actinon_hip: simple compounds: %zu entries, %zu with a verified bounding envelope, %zu again in reversed order\n", sct.size() - n_reversed, n_bounding, n_reversed );
         }
         elems2.push_back( 0 );
     }

@@ -227,13 +227,16 @@ def test_many_spheres_with_gpu_auto_envelopes(oracle):
 @pytest.mark.parametrize("spec", ["many_spheres:3:0", "many_spheres:4:1"], ids=["monte_carlo_envelopes", "analytic_envelopes"])
 def test_culled_table_walk_renders_the_same_bits(spec, monkeypatch, capfd):
     """simple_compound_hit skips an entry whose verified bounding envelope lies wholly behind the best hit so far (the
-    reference visits it: compound.c:215-243).  A skipped entry cannot hold a nearer hit, so the frame is the one of the
-    plain walk to the bit -- and the upload step does find envelopes it can verify in both ways of building the scene."""
+    reference visits it: compound.c:215-243), and walks a second table with every compound's children in reverse order when
+    the ray runs against the order of the first ("first leaf wins a tie" becomes "last visited wins").  Neither can change
+    the minimum or the leaf it belongs to, so the frame is the one of the plain walk to the bit -- and the upload step does
+    find envelopes it can verify in both ways of building the scene."""
     sc = A.Scene.build(spec, image_width=96, image_height=54, path_samples=16, direct_samples=20)
     flat = sc.flatten()
     pos = S.positions(flat)
     frames = {}
-    for label, env in (("culled", dict(ACN_VERBOSE="1")), ("plain", dict(ACN_NO_SC_CULL="1", ACN_VERBOSE="1"))):
+    for label, env in (("culled_two_orders", dict(ACN_VERBOSE="1")), ("culled_one_order", dict(ACN_NO_SC_REVERSED="1", ACN_VERBOSE="1")),
+                       ("plain", dict(ACN_NO_SC_CULL="1", ACN_VERBOSE="1"))):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         h = A.Handle(flat)
@@ -242,11 +245,14 @@ def test_culled_table_walk_renders_the_same_bits(spec, monkeypatch, capfd):
         for k in env:
             monkeypatch.delenv(k)
         err = capfd.readouterr().err
-        m = re.search(r"simple compounds: (\d+) entries, (\d+) with a verified bounding envelope", err)
+        m = re.search(r"simple compounds: (\d+) entries, (\d+) with a verified bounding envelope, (\d+) again in reversed order", err)
         assert m, err
-        assert int(m.group(1)) > 500
-        assert (int(m.group(2)) > int(m.group(1)) // 2) if label == "culled" else int(m.group(2)) == 0
-    assert np.array_equal(frames["culled"], frames["plain"])
+        entries, bounding, reversed_ = (int(m.group(k)) for k in (1, 2, 3))
+        assert entries > 500
+        assert (bounding > entries // 2) if label != "plain" else bounding == 0
+        assert reversed_ == (entries if label == "culled_two_orders" else 0)
+    assert np.array_equal(frames["culled_two_orders"], frames["plain"])
+    assert np.array_equal(frames["culled_one_order"], frames["plain"])
 
 
 def test_lanes_grid_and_walk_arrangement_do_not_change_a_pixel(oracle, monkeypatch):
