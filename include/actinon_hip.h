@@ -253,7 +253,7 @@ int acn_last_kernel_ms( acn_scene_handle* h, double* trace_ms );
 
 /* Per-stage device time of the last render call (HIP events on the launch stream; the per-stage values [0..2], [13]
  * are zero unless the call had ACN_OPT_STAGE_TIMING, the total [3] is always measured; when the call ran on concurrent
- * lanes (ACN_LANES, default 4 for large calls) the per-stage values are SUMS over the lanes and can exceed the total)
+ * lanes (ACN_LANES, default 6 for large calls) the per-stage values are SUMS over the lanes and can exceed the total)
  * and pipeline statistics:
  * out[0] walk kernels ms, [1] shade kernels ms, [2] finalize ms, [3] total ms, [4..6] launches per stage, [7] chunks,
  * [8] overflow retries, [9] path levels run, [10] peak shading tasks, [11] peak child hits, [12] slots of the largest queue,
