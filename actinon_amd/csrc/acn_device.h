@@ -801,6 +801,7 @@ template< class NP, class CT > DEV V3 roughness_normal_( NP hdr, V3 n, V3 hit_po
  * without frame, stack or nested loops. */
 #define ACN_GFLAG_LEAF_PAIR 0x100u      /* device-only bits of GNode.flags: a level-1 pair ... */
 #define ACN_GFLAG_PAIR2     0x400u      /* ... a level-2 pair: at least one operand is a level-1 pair (machines only) */
+#define ACN_GFLAG_PRUNE_LEVELS_SHIFT 12  /* bits 12 - 14: see surely_outside */
 
 template< class NP, class CT > DEV int simple_leaf_side_( NP g, V3 pos, CT* cnt )
 {
@@ -1570,16 +1571,23 @@ template< int D, class SC >
 DEV bool surely_outside( const SC& sc, int node, V3 rp, V3 rd )
 {
     auto n = &sc.nodes[ node ];
+    /* levels of this node worth reading (upload step, actinon_hip.hip): 0 nothing to test here or below, 1 only the node's own
+     * envelope, ...: the same tests as a blind descent, without the operand reads that lead to no test */
+    const uint32_t levels = ( n->flags >> ACN_GFLAG_PRUNE_LEVELS_SHIFT ) & 7u;
+    if( levels == 0 ) return false;
     if( node_has_env( n ) && !env_ray_hits_( n, rp, rd, ACN_NO_CNT ) ) return true;
     if constexpr( D > 0 )
     {
+        if( levels < 2 ) return false;
         int type = n->type;
         if( type == ACN_PAIR_OUTSIDE ) return surely_outside< D - 1 >( sc, n->child0, rp, rd ) && surely_outside< D - 1 >( sc, n->child1, rp, rd );
         if( type == ACN_PAIR_INSIDE )  return surely_outside< D - 1 >( sc, n->child0, rp, rd ) || surely_outside< D - 1 >( sc, n->child1, rp, rd );
     }
     return false;
 }
+#ifndef ACN_PRUNE_DEPTH
 #define ACN_PRUNE_DEPTH 3
+#endif
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* Interval pruning of big CSG objects.  For a root element with many nodes the upload step compiles a small postfix

@@ -589,6 +589,23 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
         memcpy( m.transparency, a.transparency, sizeof( m.transparency ) );
         m.texture = a.texture; m.pad_ = 0;
     }
+    /* surely_outside (acn_device.h) descends a pair tree up to ACN_PRUNE_DEPTH levels to test the envelopes it finds.  How many
+     * levels of a node are worth reading is known here: ACN_GFLAG_PRUNE_LEVELS( flags ) = 0 if neither the node nor any pair
+     * operand within three levels below it has an envelope, else 1 + the depth of the deepest such envelope -- the descent stops
+     * where nothing is left to test instead of reading operands for nothing (a chain of dependent scalar loads per level). */
+    if( !getenv( "ACN_NO_PRUNE_LEVELS" ) )
+    {
+        std::function< int( int32_t, int ) > deepest = [ & ]( int32_t i, int left ) -> int   /* depth of the deepest envelope within `left` levels, -1: none */
+        {
+            const acn_node& a = scene->nodes[ i ];
+            int best = ( a.flags & ACN_NODE_HAS_ENVELOPE ) ? 0 : -1;
+            if( left > 0 && ( a.type == ACN_PAIR_INSIDE || a.type == ACN_PAIR_OUTSIDE ) )
+                for( int32_t c : { a.child0, a.child1 } ) { int d = deepest( c, left - 1 ); if( d >= 0 && d + 1 > best ) best = d + 1; }
+            return best;
+        };
+        for( uint32_t i = 0; i < scene->n_nodes; i++ ) nodes[ i ].flags |= ( uint32_t )( deepest( ( int32_t )i, 3 ) + 1 ) << ACN_GFLAG_PRUNE_LEVELS_SHIFT;
+    }
+    else for( uint32_t i = 0; i < scene->n_nodes; i++ ) nodes[ i ].flags |= 4u << ACN_GFLAG_PRUNE_LEVELS_SHIFT;
     h->scene_bytes[ 0 ] = sizeof( GNode ) * scene->n_nodes; h->scene_bytes[ 1 ] = sizeof( GMat ) * scene->n_nodes;
     h->scene_bytes[ 3 ] = sizeof( acn_texture ) * ( scene->n_textures ? scene->n_textures : 1 );
     HIP_TRY_H( hipMalloc( &h->d_nodes, sizeof( GNode ) * scene->n_nodes ) );

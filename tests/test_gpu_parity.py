@@ -269,13 +269,15 @@ def test_lanes_grid_and_walk_arrangement_do_not_change_a_pixel(oracle, monkeypat
                        ("small_grid", dict(ACN_LANES="1", ACN_GRID="7", ACN_SHADE_GRID="5")),
                        ("stack_overflow", dict(ACN_LANES="1", ACN_TEST_STACK_USE="1")),
                        ("all_private", dict(ACN_LANES="1", ACN_WALK_PASSES="1")),
+                       # surely_outside descends every pair tree blindly instead of stopping where the upload step found nothing left to test
+                       ("blind_prune_descent", dict(ACN_LANES="1", ACN_NO_PRUNE_LEVELS="1")),
                        ("all_generations", dict(ACN_LANES="1", ACN_WALK_PASSES="26", ACN_PRIVATE_LIMIT="0")),
                        ("three_passes", dict(ACN_LANES="1", ACN_WALK_PASSES="3", ACN_PRIVATE_LIMIT="1000", ACN_FETCH_WALK="512")),
                        ("all", dict(ACN_LANES="3", ACN_GRID="96", ACN_TEST_STACK_USE="3", ACN_PRIVATE_LIMIT="100000")),
                        # shading tasks above 32 samples on 64 lanes instead of 16 (k_shade<64>): another summation tree
                        # for a task's samples, so equal to rounding, not to the bit
                        ("wide_tasks", dict(ACN_LANES="1", ACN_CLASS0_MIN="32"))):
-        for k in ("ACN_LANES", "ACN_GRID", "ACN_SHADE_GRID", "ACN_TEST_STACK_USE", "ACN_WALK_PASSES", "ACN_PRIVATE_LIMIT", "ACN_FETCH_WALK", "ACN_CLASS0_MIN"):
+        for k in ("ACN_LANES", "ACN_GRID", "ACN_SHADE_GRID", "ACN_TEST_STACK_USE", "ACN_WALK_PASSES", "ACN_PRIVATE_LIMIT", "ACN_FETCH_WALK", "ACN_CLASS0_MIN", "ACN_NO_PRUNE_LEVELS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)                 # read by acn_scene_upload
@@ -286,7 +288,7 @@ def test_lanes_grid_and_walk_arrangement_do_not_change_a_pixel(oracle, monkeypat
     assert frames["all_generations"][1]["private_rays"] < frames["plain"][1]["private_rays"] < frames["plain"][1]["walk_rays"]
     assert np.abs(frames["wide_tasks"][0] - frames["plain"][0]).max() <= 1e-11
     assert frames["wide_tasks"][1]["walk_rays"] == frames["plain"][1]["walk_rays"]
-    for label in ("lanes", "small_grid", "stack_overflow", "all_private", "all_generations", "three_passes", "all"):
+    for label in ("lanes", "small_grid", "stack_overflow", "all_private", "blind_prune_descent", "all_generations", "three_passes", "all"):
         assert np.array_equal(frames[label][0], frames["plain"][0]), label
         assert frames[label][1]["walk_rays"] == frames["plain"][1]["walk_rays"], label
         assert frames[label][1]["hard_rays"] == frames["plain"][1]["hard_rays"], label
