@@ -1567,10 +1567,10 @@ DEV double simple_compound_hit( const SC& sc, int cmp, V3 rp, V3 rd, V3* p_nor, 
  *   - pair_inside: one child surely outside -> it returns f3_inf and classifies every point of the ray as outside, so
  *     neither the direct candidates nor the alternating walk can accept a hit (objects.c:1057-1092), side != -2.
  * Complements and scale wrappers are never pruned.  Expanded D levels deep. */
-template< int D, class SC >
-DEV bool surely_outside( const SC& sc, int node, V3 rp, V3 rd )
+template< int D, class NP >
+DEV bool surely_outside_n( NP nodes, int node, V3 rp, V3 rd )
 {
-    auto n = &sc.nodes[ node ];
+    auto n = &nodes[ node ];
     /* levels of this node worth reading (upload step, actinon_hip.hip): 0 nothing to test here or below, 1 only the node's own
      * envelope, ...: the same tests as a blind descent, without the operand reads that lead to no test */
     const uint32_t levels = ( n->flags >> ACN_GFLAG_PRUNE_LEVELS_SHIFT ) & 7u;
@@ -1580,10 +1580,25 @@ DEV bool surely_outside( const SC& sc, int node, V3 rp, V3 rd )
     {
         if( levels < 2 ) return false;
         int type = n->type;
-        if( type == ACN_PAIR_OUTSIDE ) return surely_outside< D - 1 >( sc, n->child0, rp, rd ) && surely_outside< D - 1 >( sc, n->child1, rp, rd );
-        if( type == ACN_PAIR_INSIDE )  return surely_outside< D - 1 >( sc, n->child0, rp, rd ) || surely_outside< D - 1 >( sc, n->child1, rp, rd );
+        if( type == ACN_PAIR_OUTSIDE ) return surely_outside_n< D - 1 >( nodes, n->child0, rp, rd ) && surely_outside_n< D - 1 >( nodes, n->child1, rp, rd );
+        if( type == ACN_PAIR_INSIDE )  return surely_outside_n< D - 1 >( nodes, n->child0, rp, rd ) || surely_outside_n< D - 1 >( nodes, n->child1, rp, rd );
     }
     return false;
+}
+#ifndef ACN_PRUNE_CALL
+#define ACN_PRUNE_CALL 0
+#endif
+/* ACN_PRUNE_CALL: ONE copy of the descent per kernel behind a real call instead of one expansion per call site */
+template< int D, class NP >
+__device__ __attribute__( ( noinline ) ) bool surely_outside_call( NP nodes, int node, V3 rp, V3 rd ) { return surely_outside_n< D >( nodes, node, rp, rd ); }
+template< int D, class SC >
+DEV bool surely_outside( const SC& sc, int node, V3 rp, V3 rd )
+{
+#if ACN_PRUNE_CALL
+    return surely_outside_call< D >( sc.nodes, node, rp, rd );
+#else
+    return surely_outside_n< D >( sc.nodes, node, rp, rd );
+#endif
 }
 #ifndef ACN_PRUNE_DEPTH
 #define ACN_PRUNE_DEPTH 3
