@@ -1444,6 +1444,10 @@ static int learn_rates( acn_scene_handle* h, const double* d_pos_xy, size_t firs
     const size_t by_shadow = ( size_t )( ( double )h->ws.cap[ WQ_HARD_SHADOW ] / ( 0.25 * ( double )( h->dev.prm.direct_samples * h->n_lights + s ) + 4.0 ) );
     if( want > by_shadow ) want = by_shadow;
     if( want > 4096 ) want = 4096;
+    /* (the guess is ten times what the lamp scenes need at path_samples 1024, where it allowed 63 positions: no sample at all, and
+     * the whole hanging_lamp frame at stated size began every band with ~20 redone chunks, halving down from 92 000 positions to 9.
+     * A sample that does not fit is halved below.) */
+    if( want < 256 ) want = 256;
     if( want > n / 4 ) want = n / 4;
     const bool count_work = h->count_work, stage_timing = h->stage_timing;
     h->count_work = false; h->stage_timing = false; h->shard_rank = 0; h->shard_world = 1;
