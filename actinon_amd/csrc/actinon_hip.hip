@@ -1,5 +1,6 @@
 /* actinon_hip.hip -- libactinon_hip.so: kernels + the C ABI of include/actinon_hip.h (gfx950 only). */
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -102,6 +103,7 @@ struct Tunables
                                           13.7 -> 17 - 20 ms, c2 28.0 -> 31.9, paraffin_lamp 365 -> 400 - 450 (profiles/r04/ab_fission.txt): every lane then
                                           has two streams of persistent grids, and eight grids of 512 - 1024 workgroups take turns on one chip */
     bool     learn_sample = true;      /* ACN_LEARN_SAMPLE=0: no strided learning pass on a cold handle (learn_rates): the first chunks learn, as in round 3 */
+    bool     cold_pipeline = true;     /* ACN_COLD_PIPELINE=0: a cold handle makes its lanes before the learning pass, not beside it (render_lanes) */
     bool     count_work = false;       /* ACN_COUNT_WORK */
     bool     stage_timing = false;     /* ACN_STAGE_TIMING */
     void read()
@@ -129,6 +131,7 @@ struct Tunables
         if( const char* e = getenv( "ACN_LEARN_PASSES" ) ) learn_passes = atoi( e ) != 0;
         if( const char* e = getenv( "ACN_LEARN_GRIDS" ) ) learn_grids = atoi( e );
         if( const char* e = getenv( "ACN_LEARN_SAMPLE" ) ) learn_sample = atoi( e ) != 0;
+        if( const char* e = getenv( "ACN_COLD_PIPELINE" ) ) cold_pipeline = atoi( e ) != 0;
         if( const char* e = getenv( "ACN_SHADE_FISSION" ) ) shade_fission = atoi( e ) != 0;
         if( const char* e = getenv( "ACN_WS_UNIFORM" ) ) ws_uniform = atoi( e ) != 0;
         debug_chunks = getenv( "ACN_DEBUG_CHUNKS" ) != nullptr;
@@ -542,7 +545,8 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
 #define HIP_TRY_H( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) \
     return bail( fail( ACN_ERR_DEVICE, std::string( #expr ) + ": " + hipGetErrorString( e_ ) ) ); } while( 0 )
     HIP_TRY_H( hipStreamCreate( &h->stream ) );
-    HIP_TRY_H( hipStreamCreateWithFlags( &h->side_stream, hipStreamNonBlocking ) );
+    /* (a stream costs ~10 ms of host time to make: the second one only where it is used) */
+    if( h->tun.shade_fission ) HIP_TRY_H( hipStreamCreateWithFlags( &h->side_stream, hipStreamNonBlocking ) );
     HIP_TRY_H( hipEventCreate( &h->ev0 ) );
     HIP_TRY_H( hipEventCreate( &h->ev1 ) );
     HIP_TRY_H( hipEventCreateWithFlags( &h->ev_fork, hipEventDisableTiming ) );
@@ -1429,6 +1433,8 @@ static void set_rates( acn_scene_handle* h, uint32_t cnt, const uint32_t* fill, 
 static int learn_rates( acn_scene_handle* h, const double* d_pos_xy, size_t first, size_t n, hipStream_t stream, size_t plan_positions, unsigned plan_grid )
 {
     if( rates_known( h ) || !h->tun.learn_sample || h->tun.chunk || h->tun.ws_uniform || n < 16384 ) return ACN_OK;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [ & ]() { return std::chrono::duration< double, std::milli >( std::chrono::steady_clock::now() - t_begin ).count(); };
     int st = ensure_workspace( h, 4096 );   /* the starter set */
     if( st != ACN_OK ) return st;
     if( h->accum_cap < n )
@@ -1438,6 +1444,7 @@ static int learn_rates( acn_scene_handle* h, const double* d_pos_xy, size_t firs
         HIP_TRY( hipMalloc( &h->d_accum, sizeof( unsigned long long ) * 3 * n ) );
         h->accum_cap = n;
     }
+    if( h->tun.debug_chunks ) fprintf( stderr, "[acn sample] starter queues (%.2f GB) after %.2f ms\n", ( double )h->ws.bytes / 1e9, since() );
     /* as many positions as the starter queues hold by the guess launch_render makes for a first chunk, 4096 at most */
     const size_t s = h->dev.prm.path_samples ? h->dev.prm.path_samples : 1;
     size_t want = ( size_t )( ( double )h->ws.cap[ WQ_CHILDREN ] / ( ( double )( s + 2 ) * ( s > 64 ? ( double )s / 64.0 : 1.0 ) ) );
@@ -1465,6 +1472,8 @@ static int learn_rates( acn_scene_handle* h, const double* d_pos_xy, size_t firs
         double dead_share = 0;
         st = render_chunk( h, d_pos_xy, first, 0u, cnt, order, stream, &overflow, fill, &dead_share );
         if( st != ACN_OK ) break;
+        if( h->tun.debug_chunks )
+            fprintf( stderr, "[acn sample] chain done after %.2f ms\n", since() );
         if( h->tun.debug_chunks )
             fprintf( stderr, "[acn sample] %u positions (every %u-th) %s dead %.2f | per pos T %.1f C %.1f HS %.1f HP %.1f R %.1f\n", cnt, order.sample_stride, overflow ? "OVERFLOW" : "ok",
                      dead_share, fill[ 0 ] / ( double )cnt, fill[ 1 ] / ( double )cnt, fill[ 2 ] / ( double )cnt, fill[ 3 ] / ( double )cnt, fill[ 4 ] / ( double )cnt );
@@ -1712,12 +1721,44 @@ __global__ void k_lane_scatter( const double* __restrict__ lane_out, size_t n_la
     out_rgb[ g * 3 ] = lane_out[ i * 3 ]; out_rgb[ g * 3 + 1 ] = lane_out[ i * 3 + 1 ]; out_rgb[ g * 3 + 2 ] = lane_out[ i * 3 + 2 ];
 }
 
-static int make_lane( acn_scene_handle* parent, int lanes, acn_scene_handle** out )
+/* A lane = a clone of the handle that borrows the resident scene and owns two streams, its events, counter blocks and a host
+ * thread.  Making a stream takes ~10 ms of host time (tools/bench_alloc: 12 streams 120 - 130 ms, one after the other whatever thread
+ * asks; events, pinned memory and hipMalloc of any size are free beside that), so six lanes with two streams each were 60 - 100 ms of
+ * a handle's first call, more than its learning pass on the wine glass.  The side stream is made only where it is used
+ * (ACN_SHADE_FISSION), and so the HIP objects (lane_objects: nothing in it reads the parent) are made on a helper
+ * thread while the learning pass runs on the device (render_lanes), and the parent's fields are copied afterwards (bind_lane). */
+static int lane_objects( int device, bool side_stream, acn_scene_handle** out )
 {
     acn_scene_handle* l = new acn_scene_handle();
     l->is_lane = true;
+    l->device = device;
+#define HIP_TRY_L( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) { acn_scene_free( l ); return fail( ACN_ERR_DEVICE, hipGetErrorString( e_ ) ); } } while( 0 )
+    HIP_TRY_L( hipSetDevice( device ) );
+    HIP_TRY_L( hipStreamCreateWithFlags( &l->stream, hipStreamNonBlocking ) );
+    if( side_stream ) HIP_TRY_L( hipStreamCreateWithFlags( &l->side_stream, hipStreamNonBlocking ) );
+    HIP_TRY_L( hipEventCreate( &l->ev0 ) );
+    HIP_TRY_L( hipEventCreate( &l->ev1 ) );
+    HIP_TRY_L( hipEventCreateWithFlags( &l->ev_fork, hipEventDisableTiming ) );
+    HIP_TRY_L( hipEventCreateWithFlags( &l->ev_path, hipEventDisableTiming ) );
+    HIP_TRY_L( hipEventCreateWithFlags( &l->ev_join, hipEventDisableTiming ) );
+    HIP_TRY_L( hipMalloc( &l->d_counters, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
+    HIP_TRY_L( hipMalloc( &l->d_counters_keep, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
+    HIP_TRY_L( hipMalloc( &l->d_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
+    /* on the lane's own stream, where everything that uses them follows (the null stream would wait for the caller's) */
+    HIP_TRY_L( hipMemsetAsync( l->d_counters, 0, sizeof( unsigned long long ) * ACN_CNT_SLOTS, l->stream ) );
+    HIP_TRY_L( hipMemsetAsync( l->d_counts, 0, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS, l->stream ) );
+    HIP_TRY_L( hipHostMalloc( &l->h_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
+#undef HIP_TRY_L
+    l->worker = new LaneWorker();
+    l->worker->start();
+    *out = l;
+    return ACN_OK;
+}
+
+static unsigned lane_grid( const acn_scene_handle* parent ) { return parent->tun.grid ? parent->tun.grid : parent->cus * 1u; }
+static void bind_lane( const acn_scene_handle* parent, int lanes, acn_scene_handle* l )
+{
     l->budget_div = ( size_t )lanes;
-    l->device = parent->device;
     l->dev = parent->dev;
     l->d_nodes = parent->d_nodes; l->d_mats = parent->d_mats; l->d_elems = parent->d_elems; l->d_textures = parent->d_textures;
     l->scene_bytes[ 0 ] = parent->scene_bytes[ 0 ]; l->scene_bytes[ 1 ] = parent->scene_bytes[ 1 ]; l->scene_bytes[ 2 ] = parent->scene_bytes[ 2 ]; l->scene_bytes[ 3 ] = parent->scene_bytes[ 3 ];
@@ -1730,29 +1771,10 @@ static int make_lane( acn_scene_handle* parent, int lanes, acn_scene_handle** ou
      * four waves per SIMD a grid of 256 workgroups is resident at once, and six shorter chains fill each other's tails better than
      * four: 1080p 50.2 -> 49.1 ms, c2 26.4 -> 25.0, and the share one of 8 GPUs gets 12.25 -> 11.4 ms (profiles/r04/ab_lanes6_*).
      * A call that runs ALONE on the handle keeps four workgroups per CU (diamond on one lane: 2.3 s with them, 6.7 s with one). */
-    l->grid = parent->tun.grid ? parent->tun.grid : parent->cus * 1u;
+    l->grid = lane_grid( parent );
     l->shade_grid = parent->tun.shade_grid ? parent->tun.shade_grid : parent->cus * 3u / 2u;
     l->walk_grid = parent->tun.walk_grid ? parent->tun.walk_grid : l->grid;
-#define HIP_TRY_L( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) { acn_scene_free( l ); return fail( ACN_ERR_DEVICE, hipGetErrorString( e_ ) ); } } while( 0 )
-    HIP_TRY_L( hipStreamCreateWithFlags( &l->stream, hipStreamNonBlocking ) );
-    HIP_TRY_L( hipStreamCreateWithFlags( &l->side_stream, hipStreamNonBlocking ) );
-    HIP_TRY_L( hipEventCreate( &l->ev0 ) );
-    HIP_TRY_L( hipEventCreate( &l->ev1 ) );
-    HIP_TRY_L( hipEventCreateWithFlags( &l->ev_fork, hipEventDisableTiming ) );
-    HIP_TRY_L( hipEventCreateWithFlags( &l->ev_path, hipEventDisableTiming ) );
-    HIP_TRY_L( hipEventCreateWithFlags( &l->ev_join, hipEventDisableTiming ) );
-    HIP_TRY_L( hipMalloc( &l->d_counters, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
-    HIP_TRY_L( hipMemset( l->d_counters, 0, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
-    HIP_TRY_L( hipMalloc( &l->d_counters_keep, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
-    HIP_TRY_L( hipMalloc( &l->d_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
-    HIP_TRY_L( hipMemset( l->d_counts, 0, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
-    HIP_TRY_L( hipHostMalloc( &l->h_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
-#undef HIP_TRY_L
     l->dev.flags = l->d_counts + QC_FLAGS;
-    l->worker = new LaneWorker();
-    l->worker->start();
-    *out = l;
-    return ACN_OK;
 }
 
 /* number of lanes for a call of n positions: the handle's ACN_LANES, fewer while a lane would get less than 32 tiles or
@@ -1768,50 +1790,66 @@ static int lanes_for( const acn_scene_handle* h, size_t n )
 static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy, size_t first, size_t n, double* d_out_rgb,
                          const acn_render_opts* opts, hipStream_t stream )
 {
-    while( ( int )h->lanes.size() < lanes )
+    /* ACN_DEBUG_CHUNKS: where a call's wall time goes before and after the lanes run (one line per call on stderr) */
+    const auto t_begin = std::chrono::steady_clock::now();
+    double t_mark[ 5 ] = { 0, 0, 0, 0, 0 };
+    auto mark = [ & ]( int i ) { t_mark[ i ] = std::chrono::duration< double, std::milli >( std::chrono::steady_clock::now() - t_begin ).count(); };
+    /* the lanes this call lacks: made on a helper thread while the learning pass of a cold handle runs (see lane_objects) */
+    const int missing = lanes - ( int )h->lanes.size();
+    std::vector< acn_scene_handle* > made;
+    int made_status = ACN_OK; std::string made_message;
+    auto make_missing = [ & ]()
     {
-        acn_scene_handle* l = nullptr;
-        int st = make_lane( h, lanes, &l );
-        if( st != ACN_OK ) return st;
-        h->lanes.push_back( l );
-    }
+        for( int k = 0; k < missing && made_status == ACN_OK; k++ )
+        {
+            acn_scene_handle* l = nullptr;
+            made_status = lane_objects( h->device, h->tun.shade_fission, &l );
+            if( made_status == ACN_OK ) made.push_back( l ); else made_message = g_last_error;   /* thread-local where it was set */
+        }
+    };
+    std::thread maker;
+    const bool learn = h->lanes.empty() ? !rates_known( h ) : !rates_known( h->lanes[ 0 ] ) && !rates_known( h );
+    const bool maker_used = missing > 0 && learn && h->tun.cold_pipeline;
+    if( missing > 0 ) { if( maker_used ) maker = std::thread( make_missing ); else make_missing(); }
     /* what the caller queued on `stream` before this call must be done before the lanes read the positions */
-    HIP_TRY( hipEventRecord( h->ev0, stream ) );
-    HIP_TRY( hipEventSynchronize( h->ev0 ) );
+    hipError_t drained = hipEventRecord( h->ev0, stream );
+    if( drained == hipSuccess ) drained = hipEventSynchronize( h->ev0 );
+    mark( 0 );
     /* a cold handle learns the scene's queue demand once, for all lanes, from a sample of the call (learn_rates) */
-    if( !rates_known( h->lanes[ 0 ] ) )
+    int learned = ACN_OK;
+    if( drained == hipSuccess && learn )
     {
         h->budget_div = 1;
-        int st = learn_rates( h, d_pos_xy, first, n, stream, n / ( size_t )lanes, h->lanes[ 0 ]->grid );
-        if( st != ACN_OK ) return st;
-        HIP_TRY( hipStreamSynchronize( stream ) );
-        if( rates_known( h ) )
-        {
-            for( int k = 0; k < lanes; k++ )
-            {
-                acn_scene_handle* l = h->lanes[ k ];
-                if( rates_known( l ) ) continue;
-                for( int q = 0; q < WQ_N; q++ ) l->rate[ q ] = h->rate[ q ];
-                l->rate_cnt = h->rate_cnt; l->ctl.fill_target = h->ctl.fill_target;
-            }
-            free_workspace( h );   /* the bound is the handle's, whoever uses it */
-        }
+        learned = learn_rates( h, d_pos_xy, first, n, stream, n / ( size_t )lanes, lane_grid( h ) );
+        if( learned == ACN_OK ) drained = hipStreamSynchronize( stream );
     }
-    /* The lanes' queues are (re-)sized here, while the device is idle: hipFree synchronises the device, so lanes that
-     * re-size at the start of their chains wait for each other's chunks (second frame of paraffin_lamp 400x600, whose
-     * queues are trimmed to the rates the first frame learned: 2.1 s instead of 0.45, profiles/r03/frames_paraffin_*.txt) */
+    if( maker.joinable() ) maker.join();
+    for( acn_scene_handle* l : made ) { bind_lane( h, lanes, l ); h->lanes.push_back( l ); }
+    if( drained != hipSuccess ) return fail( ACN_ERR_DEVICE, hipGetErrorString( drained ) );
+    if( learned != ACN_OK ) return learned;
+    if( made_status != ACN_OK ) return fail( made_status, made_message );
+    /* what one arrangement learned about the scene (records per position) holds for the other */
     for( int k = 0; k < lanes; k++ )
     {
         acn_scene_handle* l = h->lanes[ k ];
-        l->budget_div = ( size_t )lanes;
-        const size_t cnt = lane_count( n, lanes, k );
-        if( cnt ) { int st = ensure_workspace( l, cnt ); if( st != ACN_OK ) return st; }
+        const acn_scene_handle* from = rates_known( h ) ? h : h->lanes[ 0 ];
+        if( rates_known( l ) || !rates_known( from ) ) continue;
+        for( int q = 0; q < WQ_N; q++ ) l->rate[ q ] = from->rate[ q ];
+        l->rate_cnt = from->rate_cnt; l->ctl.fill_target = from->ctl.fill_target;
+        for( int level = 0; level <= ACN_MAX_PATH_LEVELS; level++ ) l->walk_passes_seen[ level ] = 0;
     }
+    if( learn && rates_known( h ) ) free_workspace( h );   /* the bound is the handle's, whoever uses it */
+    /* The lanes' queues are (re-)sized here, while the device is idle: hipFree synchronises the device, so lanes that
+     * re-size at the start of their chains wait for each other's chunks (second frame of paraffin_lamp 400x600, whose
+     * queues are trimmed to the rates the first frame learned: 2.1 s instead of 0.45, profiles/r03/frames_paraffin_*.txt).
+     * hipMalloc itself is not what a first call pays: 22 GB of queues take 1 - 5 ms (tools/bench_alloc: 0.02 ms per GB; a lane that
+     * started as soon as its own queues existed gained nothing, profiles/r04/first_frames_s36_s38.txt). */
+    mark( 1 );
     acn_render_opts lane_opts{};
     if( opts ) lane_opts = *opts;
     std::vector< int > status( lanes, ACN_OK );
     std::vector< std::string > message( lanes );
-    for( int k = 0; k < lanes; k++ )
+    auto post_lane = [ & ]( int k )
     {
         h->lanes[ k ]->worker->post( [ &, k ]()
         {
@@ -1845,8 +1883,21 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
             status[ k ] = run();
             if( status[ k ] != ACN_OK ) message[ k ] = g_last_error;   /* thread-local in the worker */
         } );
+    };
+    for( int k = 0; k < lanes; k++ )
+    {
+        acn_scene_handle* l = h->lanes[ k ];
+        l->budget_div = ( size_t )lanes;
+        const size_t cnt = lane_count( n, lanes, k );
+        if( cnt ) { int st = ensure_workspace( l, cnt ); if( st != ACN_OK ) return st; }
     }
+    for( int k = 0; k < lanes; k++ ) post_lane( k );
+    mark( 2 );
     for( int k = 0; k < lanes; k++ ) h->lanes[ k ]->worker->wait();
+    mark( 3 );
+    if( h->tun.debug_chunks )
+        fprintf( stderr, "[acn call] %zu positions on %d lanes: %d lanes made%s, caller's stream drained after %.2f ms, learning pass %.2f, queues sized %.2f, lanes done %.2f\n",
+                 n, lanes, missing > 0 ? missing : 0, maker_used ? " beside the learning pass" : "", t_mark[ 0 ], t_mark[ 1 ] - t_mark[ 0 ], t_mark[ 2 ] - t_mark[ 1 ], t_mark[ 3 ] - t_mark[ 2 ] );
     for( int k = 0; k < lanes; k++ ) if( status[ k ] != ACN_OK ) return fail( status[ k ], message[ k ] );
     HIP_TRY( hipEventRecord( h->ev1, stream ) );
     /* statistics of the call: sums / maxima over the lanes */
@@ -1931,15 +1982,7 @@ static int render_dispatch( acn_scene_handle* h, const double* d_pos_xy, size_t 
         return launch_render( h, d_pos_xy, first, n, d_out_rgb, opts, stream );
     }
     free_workspace( h );
-    while( ( int )h->lanes.size() < lanes )
-    {
-        acn_scene_handle* l = nullptr;
-        int st = make_lane( h, lanes, &l );
-        if( st != ACN_OK ) return st;
-        h->lanes.push_back( l );
-    }
-    for( int k = 0; k < lanes; k++ ) inherit( h->lanes[ k ], rates_known( h ) ? h : h->lanes[ 0 ] );
-    return render_lanes( h, lanes, d_pos_xy, first, n, d_out_rgb, opts, stream );
+    return render_lanes( h, lanes, d_pos_xy, first, n, d_out_rgb, opts, stream );   /* (makes the lanes it lacks) */
 }
 
 extern "C" int acn_render_positions_dev( acn_scene_handle* h, const void* d_pos_xy, size_t n, void* d_out_rgb,

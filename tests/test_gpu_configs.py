@@ -357,6 +357,23 @@ def test_cold_handle_learns_from_a_sample_and_renders_the_same_bits(oracle, monk
     plain = h.render_positions(pos, linear=True)
     h.close()
     assert np.array_equal(first, plain)
+    # the lanes of a cold handle are made on a helper thread beside the learning pass (render_lanes / lane_objects); made before
+    # it (ACN_COLD_PIPELINE=0), or added by a later, larger call of a handle whose first call was small, they render the same bits
+    monkeypatch.delenv("ACN_LEARN_SAMPLE")
+    monkeypatch.setenv("ACN_COLD_PIPELINE", "0")
+    h = A.Handle(flat)
+    before = h.render_positions(pos, linear=True)
+    h.close()
+    assert np.array_equal(first, before)
+    monkeypatch.delenv("ACN_COLD_PIPELINE")
+    h = A.Handle(flat)
+    small = h.render_positions(pos[:20000], linear=True)          # one lane: the handle itself learns the rates
+    chunks_small = h.last_stages()["chunks"]
+    grown = h.render_positions(pos, linear=True)                  # several lanes, made now, inherit them
+    chunks_grown = h.last_stages()["chunks"]
+    h.close()
+    assert np.array_equal(first[:20000], small) and np.array_equal(first, grown)
+    assert chunks_small == 1 and chunks_grown > 1, (chunks_small, chunks_grown)     # (every lane of a call runs at least one chunk)
     stride = len(pos) // min(4096, len(pos) // 4)      # the positions the learning pass rendered and cleared
     sample = np.arange(0, len(pos), stride)[:512]
     cpu = oracle.render_positions(flat, pos[sample], linear=True)
