@@ -510,10 +510,13 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     if( ndev <= 0 ) return fail( ACN_ERR_DEVICE, "no HIP device (libactinon_hip has no CPU fallback)" );
     if( device < 0 || device >= ndev ) return fail( ACN_ERR_ARG, "bad device index" );
     HIP_TRY( hipSetDevice( device ) );
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [ & ]() { return std::chrono::duration< double, std::milli >( std::chrono::steady_clock::now() - t_begin ).count(); };
     acn_scene_handle* h = new acn_scene_handle();
     h->device = device;
     h->max_csg_depth = max_csg;
     h->tun.read();
+    double t_up[ 4 ] = { 0, 0, 0, 0 };   /* ACN_DEBUG_CHUNKS: stream + events, host-side tables, device copies, the camera kernel */
     {
         /* Workspace BOUND of the handle: ACN_WORKSPACE_MB, or 64 GiB / a quarter of the free device memory (288 GB per
          * MI355X).  It is a bound, not an allocation: the queues are sized from measured demand (ensure_workspace) and take
@@ -544,7 +547,9 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     auto bail = [ & ]( int code ) { acn_scene_free( h ); return code; };
 #define HIP_TRY_H( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) \
     return bail( fail( ACN_ERR_DEVICE, std::string( #expr ) + ": " + hipGetErrorString( e_ ) ) ); } while( 0 )
+    const double t_stream0 = since();
     HIP_TRY_H( hipStreamCreate( &h->stream ) );
+    const double t_stream1 = since();   /* (the first stream a process makes: 85 - 100 ms on this runtime; later ones ~10) */
     /* (a stream costs ~10 ms of host time to make: the second one only where it is used) */
     if( h->tun.shade_fission ) HIP_TRY_H( hipStreamCreateWithFlags( &h->side_stream, hipStreamNonBlocking ) );
     HIP_TRY_H( hipEventCreate( &h->ev0 ) );
@@ -612,6 +617,7 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     else for( uint32_t i = 0; i < scene->n_nodes; i++ ) nodes[ i ].flags |= 4u << ACN_GFLAG_PRUNE_LEVELS_SHIFT;
     h->scene_bytes[ 0 ] = sizeof( GNode ) * scene->n_nodes; h->scene_bytes[ 1 ] = sizeof( GMat ) * scene->n_nodes;
     h->scene_bytes[ 3 ] = sizeof( acn_texture ) * ( scene->n_textures ? scene->n_textures : 1 );
+    t_up[ 0 ] = since();
     HIP_TRY_H( hipMalloc( &h->d_nodes, sizeof( GNode ) * scene->n_nodes ) );
     HIP_TRY_H( hipMalloc( &h->d_mats, sizeof( GMat ) * scene->n_nodes ) );
     /* elems[ 0 .. n ) as given; elems[ n .. 2n ) the same slices with each compound's elements ordered by estimated
@@ -882,6 +888,7 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     h->scene_bytes[ 2 ] = sizeof( int32_t ) * elems2.size();
     HIP_TRY_H( hipMalloc( &h->d_elems, sizeof( int32_t ) * elems2.size() ) );
     HIP_TRY_H( hipMalloc( &h->d_sc_table, sizeof( SCEntry ) * ( sc_table.size() ? sc_table.size() : 1 ) ) );
+    t_up[ 1 ] = since();
     if( sc_table.size() ) HIP_TRY_H( hipMemcpy( h->d_sc_table, sc_table.data(), sizeof( SCEntry ) * sc_table.size(), hipMemcpyHostToDevice ) );
     h->dev.sc_table = h->d_sc_table;
     HIP_TRY_H( hipMalloc( &h->d_sc_spheres, sizeof( double ) * ( sc_spheres.size() ? sc_spheres.size() : 4 ) ) );
@@ -962,6 +969,7 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
         M3* d_rot = nullptr; double* d_uf = nullptr;
         HIP_TRY_H( hipMalloc( &d_rot, sizeof( M3 ) ) );
         HIP_TRY_H( hipMalloc( &d_uf, sizeof( double ) ) );
+        t_up[ 2 ] = since();
         hipLaunchKernelGGL( k_camera_setup, dim3( 1 ), dim3( 1 ), 0, h->stream, h->dev, d_rot, d_uf );
         HIP_TRY_H( hipGetLastError() );
         HIP_TRY_H( hipStreamSynchronize( h->stream ) );
@@ -969,6 +977,9 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
         HIP_TRY_H( hipMemcpy( &h->dev.unit_f, d_uf, sizeof( double ), hipMemcpyDeviceToHost ) );
         hipFree( d_rot ); hipFree( d_uf );
     }
+    if( h->tun.debug_chunks )
+        fprintf( stderr, "[acn upload] %u nodes: the handle's stream %.2f ms, events %.2f, tables on the host %.2f, device copies %.2f, first kernel of the library (camera set-up) %.2f\n",
+                 ( unsigned )scene->n_nodes, t_stream1 - t_stream0, t_up[ 0 ] - t_stream1 + t_stream0, t_up[ 1 ] - t_up[ 0 ], t_up[ 2 ] - t_up[ 1 ], since() - t_up[ 2 ] );
     *out = h;
     return ACN_OK;
 }
@@ -1727,30 +1738,39 @@ __global__ void k_lane_scatter( const double* __restrict__ lane_out, size_t n_la
  * a handle's first call, more than its learning pass on the wine glass.  The side stream is made only where it is used
  * (ACN_SHADE_FISSION), and so the HIP objects (lane_objects: nothing in it reads the parent) are made on a helper
  * thread while the learning pass runs on the device (render_lanes), and the parent's fields are copied afterwards (bind_lane). */
-static int lane_objects( int device, bool side_stream, acn_scene_handle** out )
+static int lane_objects( int device, bool side_stream, bool debug, acn_scene_handle** out )
 {
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [ & ]() { return std::chrono::duration< double, std::milli >( std::chrono::steady_clock::now() - t_begin ).count(); };
+    double t[ 5 ] = { 0, 0, 0, 0, 0 };
     acn_scene_handle* l = new acn_scene_handle();
     l->is_lane = true;
     l->device = device;
 #define HIP_TRY_L( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) { acn_scene_free( l ); return fail( ACN_ERR_DEVICE, hipGetErrorString( e_ ) ); } } while( 0 )
     HIP_TRY_L( hipSetDevice( device ) );
+    t[ 0 ] = since();
     HIP_TRY_L( hipStreamCreateWithFlags( &l->stream, hipStreamNonBlocking ) );
+    t[ 1 ] = since();
     if( side_stream ) HIP_TRY_L( hipStreamCreateWithFlags( &l->side_stream, hipStreamNonBlocking ) );
     HIP_TRY_L( hipEventCreate( &l->ev0 ) );
     HIP_TRY_L( hipEventCreate( &l->ev1 ) );
     HIP_TRY_L( hipEventCreateWithFlags( &l->ev_fork, hipEventDisableTiming ) );
     HIP_TRY_L( hipEventCreateWithFlags( &l->ev_path, hipEventDisableTiming ) );
     HIP_TRY_L( hipEventCreateWithFlags( &l->ev_join, hipEventDisableTiming ) );
+    t[ 2 ] = since();
     HIP_TRY_L( hipMalloc( &l->d_counters, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
     HIP_TRY_L( hipMalloc( &l->d_counters_keep, sizeof( unsigned long long ) * ACN_CNT_SLOTS ) );
     HIP_TRY_L( hipMalloc( &l->d_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
     /* on the lane's own stream, where everything that uses them follows (the null stream would wait for the caller's) */
     HIP_TRY_L( hipMemsetAsync( l->d_counters, 0, sizeof( unsigned long long ) * ACN_CNT_SLOTS, l->stream ) );
     HIP_TRY_L( hipMemsetAsync( l->d_counts, 0, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS, l->stream ) );
+    t[ 3 ] = since();
     HIP_TRY_L( hipHostMalloc( &l->h_counts, sizeof( uint32_t ) * QC_N * ACN_LEVEL_BLOCKS ) );
+    t[ 4 ] = since();
 #undef HIP_TRY_L
     l->worker = new LaneWorker();
     l->worker->start();
+    if( debug ) fprintf( stderr, "[acn lane] set device %.2f ms, stream %.2f, events %.2f, counter blocks + memsets %.2f, pinned block %.2f, thread %.2f\n", t[ 0 ], t[ 1 ] - t[ 0 ], t[ 2 ] - t[ 1 ], t[ 3 ] - t[ 2 ], t[ 4 ] - t[ 3 ], since() - t[ 4 ] );
     *out = l;
     return ACN_OK;
 }
@@ -1803,7 +1823,7 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
         for( int k = 0; k < missing && made_status == ACN_OK; k++ )
         {
             acn_scene_handle* l = nullptr;
-            made_status = lane_objects( h->device, h->tun.shade_fission, &l );
+            made_status = lane_objects( h->device, h->tun.shade_fission, h->tun.debug_chunks, &l );
             if( made_status == ACN_OK ) made.push_back( l ); else made_message = g_last_error;   /* thread-local where it was set */
         }
     };

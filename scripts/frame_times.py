@@ -14,7 +14,10 @@ if builder.startswith("fixture:"):
 else:
     flat = A.Scene.build(builder, **ov).flatten()
 w, h = int(flat.params.image_width), int(flat.params.image_height)
+torch.cuda.synchronize()
+t_up = time.perf_counter()
 hd = A.Handle(flat)
+t_up = (time.perf_counter() - t_up) * 1e3
 out = torch.empty((w * h, 3), dtype=torch.float64, device="cuda:0")
 line = []
 for f in range(frames):
@@ -25,7 +28,7 @@ for f in range(frames):
     dt = (time.perf_counter() - t0) * 1e3
     st = hd.last_stages()
     line.append("%.1f ms (chunks %d, retries %d, walk launches %d, ws %.2f GB, allocs %s)" % (dt, st["chunks"], st["retries"], st["walk_launches"], st.get("workspace_bytes", 0) / 1e9, st.get("workspace_allocs", "-")))
-print(name, os.getcwd().split("/")[-1] or "repo")
+print(name, os.getcwd().split("/")[-1] or "repo", "   upload (acn_scene_upload, first HIP work of the library in this process): %.1f ms" % t_up)
 for l in line:
     print("   ", l)
 hd.close()

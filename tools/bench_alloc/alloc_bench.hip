@@ -99,7 +99,7 @@ int main()
     {
         hipStream_t st[ 12 ]; hipEvent_t ev[ 30 ]; void* hp[ 6 ]; unsigned long long* d; CK( hipMalloc( &d, 8 ) );
         double t0 = now_ms();
-        for( int k = 0; k < 12; k++ ) CK( hipStreamCreateWithFlags( &st[ k ], hipStreamNonBlocking ) );
+        for( int k = 0; k < 12; k++ ) { double a = now_ms(); CK( hipStreamCreateWithFlags( &st[ k ], hipStreamNonBlocking ) ); printf( "stream %d: %.2f ms\n", k + 1, now_ms() - a ); }
         double t1 = now_ms();
         for( int k = 0; k < 30; k++ ) CK( hipEventCreate( &ev[ k ] ) );
         double t2 = now_ms();
