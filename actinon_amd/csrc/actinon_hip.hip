@@ -104,6 +104,13 @@ struct Tunables
                                           has two streams of persistent grids, and eight grids of 512 - 1024 workgroups take turns on one chip */
     bool     learn_sample = true;      /* ACN_LEARN_SAMPLE=0: no strided learning pass on a cold handle (learn_rates): the first chunks learn, as in round 3 */
     bool     cold_pipeline = true;     /* ACN_COLD_PIPELINE=0: a cold handle makes its lanes before the learning pass, not beside it (render_lanes) */
+    bool     early_lanes = false;      /* ACN_EARLY_LANES=1: the lanes a whole frame of the scene's own raster will use are made during acn_scene_upload (a
+                                          helper thread beside the upload's own work, while the device is idle), not by the first call that needs them.
+                                          Measured and OFF (profiles/r04/ab_early_lanes_s42.txt): the streams cost the same ~10 ms each wherever they are made
+                                          and do not overlap the handle's own first stream, so the upload grows by 50 - 90 ms while the first frame loses
+                                          20 - 100 (1080p 114 - 174 -> 72 - 75 ms, c2 94 - 135 -> 48 - 49, paraffin_lamp 486 - 504 -> 466 - 479, hanging_lamp
+                                          417 - 426 -> 390 - 401); upload + first frame: 1080p 247 - 299 -> 277 - 323 ms, c2 189 - 261 -> 195 - 204, the
+                                          lamps +30.  For a host that uploads long before it renders */
     bool     count_work = false;       /* ACN_COUNT_WORK */
     bool     stage_timing = false;     /* ACN_STAGE_TIMING */
     void read()
@@ -132,6 +139,7 @@ struct Tunables
         if( const char* e = getenv( "ACN_LEARN_GRIDS" ) ) learn_grids = atoi( e );
         if( const char* e = getenv( "ACN_LEARN_SAMPLE" ) ) learn_sample = atoi( e ) != 0;
         if( const char* e = getenv( "ACN_COLD_PIPELINE" ) ) cold_pipeline = atoi( e ) != 0;
+        if( const char* e = getenv( "ACN_EARLY_LANES" ) ) early_lanes = atoi( e ) != 0;
         if( const char* e = getenv( "ACN_SHADE_FISSION" ) ) shade_fission = atoi( e ) != 0;
         if( const char* e = getenv( "ACN_WS_UNIFORM" ) ) ws_uniform = atoi( e ) != 0;
         debug_chunks = getenv( "ACN_DEBUG_CHUNKS" ) != nullptr;
@@ -227,6 +235,10 @@ struct acn_scene_handle
     bool is_lane = false;
     size_t budget_div = 1;                     /* workspace budget of a lane = the handle's budget / lanes */
     std::vector< acn_scene_handle* > lanes;
+    /* lanes made during acn_scene_upload on a helper thread (early_lanes_begin), taken over by the first call that runs on lanes */
+    std::thread early_maker;
+    std::vector< acn_scene_handle* > early_made;
+    int early_status = 0; std::string early_message;
     LaneWorker* worker = nullptr;              /* of a lane */
     size_t scene_bytes[ 4 ] = { 0, 0, 0, 0 };
     double* d_lane_pos = nullptr; double* d_lane_out = nullptr; size_t lane_buf_cap = 0;   /* a lane's gathered positions / results */
@@ -499,6 +511,33 @@ extern "C" int acn_device_count( void )
     return n;
 }
 
+static int lane_objects( int device, bool side_stream, bool debug, acn_scene_handle** out );
+static int lanes_for_counts( int tun_lanes, size_t n, uint64_t path_samples );
+
+/* Lanes made during the upload.  A stream that gets its own hardware queue costs ~10 ms of host time, and making one while kernels
+ * run stretches those kernels too (the learning pass of a cold handle: 19 ms alone, 56 - 150 ms beside six streams being made,
+ * profiles/r04/upload_timeline_s41.txt) -- so the lanes a whole frame of the scene's own raster will use are made here, on a helper
+ * thread beside the upload's host work and copies, while nothing of this handle runs on the device (ACN_EARLY_LANES=1; off by
+ * default: the runtime makes streams one after the other, so the time only moves from the first call into the upload).  A handle that would render its
+ * raster on one lane (small rasters, path_samples >= 256 on a cold handle: render_positions) makes none.  Failures are not reported
+ * from here: the first call that needs the lanes makes what is missing and reports its own. */
+static void early_lanes_begin( acn_scene_handle* h, size_t n, uint64_t path_samples )
+{
+    const int lanes = lanes_for_counts( h->tun.lanes, n, path_samples );
+    if( lanes <= 1 || path_samples >= 256 ) return;
+    const int device = h->device; const bool side = h->tun.shade_fission, debug = h->tun.debug_chunks;
+    h->early_maker = std::thread( [ h, lanes, device, side, debug ]()
+    {
+        for( int k = 0; k < lanes; k++ )
+        {
+            acn_scene_handle* l = nullptr;
+            if( lane_objects( device, side, debug, &l ) != ACN_OK ) break;
+            h->early_made.push_back( l );
+        }
+    } );
+}
+static void early_lanes_join( acn_scene_handle* h ) { if( h->early_maker.joinable() ) h->early_maker.join(); }
+
 extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_scene_handle** out )
 {
     if( !out ) return fail( ACN_ERR_ARG, "null out" );
@@ -516,6 +555,7 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
     h->device = device;
     h->max_csg_depth = max_csg;
     h->tun.read();
+    if( h->tun.early_lanes ) early_lanes_begin( h, ( size_t )scene->params.image_width * ( size_t )scene->params.image_height, scene->params.path_samples );
     double t_up[ 4 ] = { 0, 0, 0, 0 };   /* ACN_DEBUG_CHUNKS: stream + events, host-side tables, device copies, the camera kernel */
     {
         /* Workspace BOUND of the handle: ACN_WORKSPACE_MB, or 64 GiB / a quarter of the free device memory (288 GB per
@@ -970,6 +1010,8 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
         HIP_TRY_H( hipMalloc( &d_rot, sizeof( M3 ) ) );
         HIP_TRY_H( hipMalloc( &d_uf, sizeof( double ) ) );
         t_up[ 2 ] = since();
+        early_lanes_join( h );   /* before the first kernel: nothing of this handle runs while hardware queues are being made */
+        t_up[ 3 ] = since();
         hipLaunchKernelGGL( k_camera_setup, dim3( 1 ), dim3( 1 ), 0, h->stream, h->dev, d_rot, d_uf );
         HIP_TRY_H( hipGetLastError() );
         HIP_TRY_H( hipStreamSynchronize( h->stream ) );
@@ -978,8 +1020,8 @@ extern "C" int acn_scene_upload( const acn_flat_scene* scene, int device, acn_sc
         hipFree( d_rot ); hipFree( d_uf );
     }
     if( h->tun.debug_chunks )
-        fprintf( stderr, "[acn upload] %u nodes: the handle's stream %.2f ms, events %.2f, tables on the host %.2f, device copies %.2f, first kernel of the library (camera set-up) %.2f\n",
-                 ( unsigned )scene->n_nodes, t_stream1 - t_stream0, t_up[ 0 ] - t_stream1 + t_stream0, t_up[ 1 ] - t_up[ 0 ], t_up[ 2 ] - t_up[ 1 ], since() - t_up[ 2 ] );
+        fprintf( stderr, "[acn upload] %u nodes: the handle's stream %.2f ms, events %.2f, tables on the host %.2f, device copies %.2f, waited for %d early lanes %.2f, first kernel of the library (camera set-up) %.2f\n",
+                 ( unsigned )scene->n_nodes, t_stream1 - t_stream0, t_up[ 0 ] - t_stream1 + t_stream0, t_up[ 1 ] - t_up[ 0 ], t_up[ 2 ] - t_up[ 1 ], ( int )h->early_made.size(), t_up[ 3 ] - t_up[ 2 ], since() - t_up[ 3 ] );
     *out = h;
     return ACN_OK;
 }
@@ -1001,6 +1043,9 @@ extern "C" void acn_scene_free( acn_scene_handle* h )
 {
     if( !h ) return;
     hipSetDevice( h->device );
+    early_lanes_join( h );
+    for( acn_scene_handle* l : h->early_made ) acn_scene_free( l );
+    h->early_made.clear();
     for( acn_scene_handle* l : h->lanes ) acn_scene_free( l );
     h->lanes.clear();
     if( h->worker ) { h->worker->stop(); delete h->worker; h->worker = nullptr; }
@@ -1799,13 +1844,14 @@ static void bind_lane( const acn_scene_handle* parent, int lanes, acn_scene_hand
 
 /* number of lanes for a call of n positions: the handle's ACN_LANES, fewer while a lane would get less than 32 tiles or
  * less than ~10^6 path samples' worth of work (a frame without path tracing is over before a second lane has started) */
-static int lanes_for( const acn_scene_handle* h, size_t n )
+static int lanes_for_counts( int tun_lanes, size_t n, uint64_t path_samples )
 {
-    int lanes = h->tun.lanes;
-    const size_t work = n * ( size_t )( h->dev.prm.path_samples + 1 );
+    int lanes = tun_lanes;
+    const size_t work = n * ( size_t )( path_samples + 1 );
     while( lanes > 1 && ( n < ( size_t )lanes * 32 * ACN_LANE_TILE || work < ( size_t )lanes << 20 ) ) lanes--;
     return lanes;
 }
+static int lanes_for( const acn_scene_handle* h, size_t n ) { return lanes_for_counts( h->tun.lanes, n, h->dev.prm.path_samples ); }
 
 static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy, size_t first, size_t n, double* d_out_rgb,
                          const acn_render_opts* opts, hipStream_t stream )
@@ -1815,6 +1861,9 @@ static int render_lanes( acn_scene_handle* h, int lanes, const double* d_pos_xy,
     double t_mark[ 5 ] = { 0, 0, 0, 0, 0 };
     auto mark = [ & ]( int i ) { t_mark[ i ] = std::chrono::duration< double, std::milli >( std::chrono::steady_clock::now() - t_begin ).count(); };
     /* the lanes this call lacks: made on a helper thread while the learning pass of a cold handle runs (see lane_objects) */
+    early_lanes_join( h );
+    for( acn_scene_handle* l : h->early_made ) { bind_lane( h, lanes, l ); h->lanes.push_back( l ); }   /* made during the upload */
+    h->early_made.clear();
     const int missing = lanes - ( int )h->lanes.size();
     std::vector< acn_scene_handle* > made;
     int made_status = ACN_OK; std::string made_message;

@@ -374,7 +374,19 @@ def test_cold_handle_learns_from_a_sample_and_renders_the_same_bits(oracle, monk
     h.close()
     assert np.array_equal(first[:20000], small) and np.array_equal(first, grown)
     assert chunks_small == 1 and chunks_grown > 1, (chunks_small, chunks_grown)     # (every lane of a call runs at least one chunk)
-    stride = len(pos) // min(4096, len(pos) // 4)      # the positions the learning pass rendered and cleared
+    # lanes made during acn_scene_upload (ACN_EARLY_LANES=1, early_lanes_begin): adopted by the first call on lanes, unused by a
+    # one-lane call, freed with a handle that never rendered
+    monkeypatch.setenv("ACN_EARLY_LANES", "1")
+    A.Handle(flat).close()
+    h = A.Handle(flat)
+    small_early = h.render_positions(pos[:20000], linear=True)
+    early = h.render_positions(pos, linear=True)
+    st_early = h.last_stages()
+    h.close()
+    monkeypatch.delenv("ACN_EARLY_LANES")
+    assert np.array_equal(first[:20000], small_early) and np.array_equal(first, early)
+    assert st_early["chunks"] > 1 and st_early["retries"] == 0, st_early
+    stride =len(pos) // min(4096, len(pos) // 4)      # the positions the learning pass rendered and cleared
     sample = np.arange(0, len(pos), stride)[:512]
     cpu = oracle.render_positions(flat, pos[sample], linear=True)
     assert np.abs(first[sample] - cpu).max() <= TOL
